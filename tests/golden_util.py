@@ -1,0 +1,90 @@
+"""Load the golden vectors written by oracle/gen_golden.py (outputs of the reference itself)."""
+
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names(prefix=""):
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in names if n != "ala_dipeptide_pdb"]
+
+
+def load_meta():
+    with open(os.path.join(GOLDEN_DIR, "reference_meta.json")) as fh:
+        return json.load(fh)
+
+
+class Case(object):
+    """One golden case: the constructor index lists, the input and the reference's outputs."""
+
+    def __init__(self, name):
+        self.name = name
+        d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.kind = str(d["kind"])
+        self.n_inp = int(d["n_inp"])
+        self.input_ix = d["input_ix"].tolist()
+        self.use_angle_value = bool(d["use_angle_value"])
+        self.out_f32 = torch.from_numpy(d["out_f32"])
+        self.out_f64 = torch.from_numpy(d["out_f64"])
+        if "x" in d:
+            self.x = torch.from_numpy(d["x"])
+        else:
+            from molann_amd import workloads as wl
+            r = json.loads(str(d["x_recipe"]))
+            self.x = wl.get_workload(r["workload"]).make_frames(r["frames"], seed=r["seed"])
+            assert abs(float(self.x.double().sum()) - float(d["x_checksum"])) < 1e-6 * max(1.0, abs(float(d["x_checksum"])))
+            assert np.array_equal(self.x[0, :4].numpy(), d["x_first"])
+        self.has_align = "align_local" in d
+        if self.has_align:
+            self.align_numbers = d["align_numbers"].tolist()
+            self.align_local = d["align_local"].tolist()
+            self.ref_pos = torch.from_numpy(d["ref_pos"])
+            self.ref_x = torch.from_numpy(d["ref_x"])
+        self.features = []
+        self.features_numbers = []
+        if "feat_types" in d:
+            ptr = d["feat_ptr"]
+            for i, t in enumerate(d["feat_types"].tolist()):
+                self.features.append((int(t), d["feat_local"][ptr[i]:ptr[i + 1]].tolist()))
+                self.features_numbers.append((int(t), d["feat_numbers"][ptr[i]:ptr[i + 1]].tolist()))
+            self.feat_dims = d["feat_dims"].tolist()
+            self.feature_dim = int(d["feature_dim"])
+        self.mlp_dims = d["mlp_dims"].tolist() if "mlp_dims" in d else None
+        self.activation = str(d["activation"]) if "activation" in d else "tanh"
+        self.weights, self.biases = None, None
+        if self.mlp_dims is not None:
+            src = d
+            if "W0" not in d:       # the bf16-weight C5 case reuses molann_C5_small's weights, rounded
+                src = np.load(os.path.join(GOLDEN_DIR, "molann_C5_small.npz"))
+            self.weights = [torch.from_numpy(src["W%d" % i]) for i in range(len(self.mlp_dims) - 1)]
+            self.biases = [torch.from_numpy(src["b%d" % i]) for i in range(len(self.mlp_dims) - 1)]
+            if "W0" not in d:
+                self.weights = [w.to(torch.bfloat16).to(torch.float32) for w in self.weights]
+                self.biases = [b.to(torch.bfloat16).to(torch.float32) for b in self.biases]
+        self.state_dict_keys = d["state_dict_keys"].tolist() if "state_dict_keys" in d else None
+
+    def oracle(self, dtype=torch.float32):
+        """The oracle's answer for this case in the given dtype."""
+        from oracle import molann_oracle as mo
+        x = self.x.to(dtype)
+        ref_x = self.ref_x.to(dtype) if self.has_align else None
+        al = self.align_local if self.has_align else None
+        if self.kind == "align":
+            return mo.align_forward(x, al, ref_x)
+        if self.kind == "features":
+            return mo.preprocessing_forward(x, self.features, self.use_angle_value, al, ref_x)
+        ws = [w.to(dtype) for w in self.weights]
+        bs = [b.to(dtype) for b in self.biases]
+        return mo.molann_forward(x, self.features, ws, bs, self.use_angle_value, al, ref_x, self.activation)
+
+    def tolerance_vs_f32(self):
+        """|build - ref32| bound: 1e-5 (BASELINE.json), widened where the reference's own fp32
+        run is further than that from its fp64 run (hard part 1)."""
+        own = float((self.out_f32.double() - self.out_f64).abs().max()) if self.out_f32.numel() else 0.0
+        return max(1e-5, 2.0 * own)
