@@ -1,0 +1,168 @@
+/*
+ * molann_hip.h - C ABI of the MI355X (gfx950) implementation of molann's per-frame forward path
+ *
+ *     x[N, n_inp, 3]  ->  AlignmentLayer (Kabsch)  ->  FeatureLayer  ->  MLP  ->  y[N, d_out]
+ *
+ * The reference (zwpku/molann v1.1.7) is pure Python: it has no FFI for this path.  The interface a
+ * replacement sits behind is the forward of its torch.nn.Modules (molann/ann.py); each entry point
+ * below names the reference method it replaces.  A host binding (ctypes, see INTEGRATION.md, and
+ * molann_amd/_capi.py) builds one immutable plan per module and then calls the launch functions with
+ * raw device pointers.
+ *
+ * Conventions
+ *   - return value: 0 = ok; negative = MOLANN_E_* (bad argument / unsupported); positive = hipError_t.
+ *   - every `x`, `out`, `W[i]`, `b[i]`, `ref_x` passed to a LAUNCH function is a DEVICE pointer owned
+ *     by the caller; pointers inside molann_plan_desc are HOST pointers, read during plan_create only.
+ *   - launch functions only enqueue work on `stream`: no host synchronisation, no allocation
+ *     (graph-capturable).  They are thread-safe for distinct plans; one plan may be used from several
+ *     streams as long as molann_plan_update_* calls are ordered before the launches that need them.
+ *   - x is [n_frames, n_inp, 3] fp32, contiguous, frame-major / atom-major / xyz-minor (the layout of
+ *     the tensor the reference's forward receives, ann.py:170).  Any 4-byte aligned pointer works;
+ *     16-byte aligned pointers take the wide-load path.
+ *   - n_frames == 0 is legal and does nothing (the reference returns an empty tensor).
+ *   - code object: gfx950 only.
+ */
+#ifndef MOLANN_HIP_H
+#define MOLANN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOLANN_ABI_VERSION 1
+
+/* feature type ids: molann/feature.py:87-97 */
+#define MOLANN_FEAT_ANGLE 0
+#define MOLANN_FEAT_BOND 1
+#define MOLANN_FEAT_DIHEDRAL 2
+#define MOLANN_FEAT_POSITION 3
+
+/* activation between the Linear layers of create_sequential_nn (ann.py:37,64) */
+#define MOLANN_ACT_TANH 0
+#define MOLANN_ACT_RELU 1
+#define MOLANN_ACT_SIGMOID 2
+#define MOLANN_ACT_IDENTITY 3
+#define MOLANN_ACT_ELU 4
+#define MOLANN_ACT_SILU 5
+#define MOLANN_ACT_SOFTPLUS 6
+#define MOLANN_ACT_LEAKY_RELU 7 /* slope 0.01 */
+#define MOLANN_ACT_GELU 8       /* erf form (torch.nn.GELU default) */
+
+/* MLP arithmetic */
+#define MOLANN_MLP_F32 0  /* fp32 weights, fp32 FMA / fp32-input MFMA (exact fp32) */
+#define MOLANN_MLP_BF16 1 /* bf16 weights + activations, fp32 accumulate on bf16 MFMA */
+
+#define MOLANN_MAX_LAYERS 16
+
+/* error codes (negative) */
+#define MOLANN_OK 0
+#define MOLANN_E_NULL (-1)        /* a required pointer is NULL */
+#define MOLANN_E_DESC (-2)        /* inconsistent plan description (sizes, counts) */
+#define MOLANN_E_INDEX (-3)       /* an atom index is outside [0, n_inp) */
+#define MOLANN_E_FEATURE (-4)     /* unknown feature type or wrong atom count for its type */
+#define MOLANN_E_STAGE (-5)       /* the plan lacks the stage this call needs (no align / features / MLP) */
+#define MOLANN_E_ALIGNMENT (-6)   /* pointer not 4-byte aligned */
+#define MOLANN_E_UNSUPPORTED (-7) /* shape outside what the kernels cover */
+#define MOLANN_E_NOT_PACKED (-8)  /* forward_packed before any plan_update_mlp */
+#define MOLANN_E_DEVICE (-9)      /* no gfx950 device */
+
+typedef struct molann_plan molann_plan;         /* opaque; owns a small device blob */
+typedef struct ihipStream_t* molann_stream_t;   /* == hipStream_t */
+
+/*
+ * Everything the modules fix at construction time.
+ *   AlignmentLayer.__init__  ann.py:123-146  -> n_align, align_idx (= _local_align_atom_indices), ref_x
+ *   FeatureMap.__init__      ann.py:244-263  -> feat_type / feat_idx (= _local_atom_indices), use_angle_value
+ *   FeatureLayer.__init__    ann.py:418-427  -> the list order = output column order (ann.py:473)
+ *   create_sequential_nn     ann.py:37-67    -> layer_dims, activation
+ * A stage that is absent has its count set to 0.
+ */
+typedef struct molann_plan_desc {
+    int32_t abi_version;       /* MOLANN_ABI_VERSION */
+    int32_t n_inp;             /* atoms per frame, ann.py:133 */
+
+    int32_t n_align;           /* 0: no AlignmentLayer (PreprocessingANN uses Identity, ann.py:542) */
+    const int32_t* align_idx;  /* [n_align] positions inside the n_inp axis, ann.py:144 */
+    const float* ref_x;        /* [n_align*3] reference coordinates ALREADY centred, ann.py:140-141 */
+
+    int32_t n_features;        /* 0: no FeatureLayer */
+    const int32_t* feat_type;  /* [n_features] MOLANN_FEAT_* */
+    const int32_t* feat_ptr;   /* [n_features+1] offsets into feat_idx */
+    const int32_t* feat_idx;   /* positions inside the n_inp axis, ann.py:261, in the order given */
+    int32_t use_angle_value;   /* ann.py:253 */
+
+    int32_t n_layers;          /* number of Linear layers; 0: no MLP */
+    const int32_t* layer_dims; /* [n_layers+1]; layer_dims[0] must equal the feature dimension */
+    int32_t activation;        /* MOLANN_ACT_* */
+    int32_t mlp_precision;     /* MOLANN_MLP_* */
+} molann_plan_desc;
+
+/* -- plan ------------------------------------------------------------------------------------- */
+
+/* Validates the description (the reference raises ValueError / AssertionError for the same
+ * conditions at module construction, ann.py:146,263,423 and feature.py:88-94), copies it to the
+ * current device and returns the plan.  Allocates; call once per module. */
+int molann_plan_create(const molann_plan_desc* desc, molann_plan** out_plan);
+int molann_plan_destroy(molann_plan* plan);
+
+/* FeatureLayer.output_dimension() ann.py:446-452 (0 when the plan has no features). */
+int molann_plan_feature_dim(const molann_plan* plan);
+/* Width of what molann_forward_* writes: last layer_dims entry, or the feature dim without an MLP. */
+int molann_plan_out_dim(const molann_plan* plan);
+/* Which kernel family serves the frames of this plan: 0 = lane-per-frame (LDS-staged small frames),
+ * 1 = wave-per-frame (gathered large frames). */
+int molann_plan_kernel_family(const molann_plan* plan);
+
+/* The module's `ref_x` buffer is live state (register_buffer, ann.py:137: load_state_dict / .to()
+ * can replace it).  Re-reads it from DEVICE memory [n_align*3], already centred. */
+int molann_plan_update_ref(molann_plan* plan, const float* ref_x, molann_stream_t stream);
+
+/* The Linear parameters are live (trainable).  Re-reads W[i] ([dims[i+1], dims[i]] row-major,
+ * torch.nn.Linear layout) and b[i] ([dims[i+1]]) from DEVICE memory into the plan's packed copy.
+ * W and b themselves are HOST arrays of n_layers device pointers. */
+int molann_plan_update_mlp(molann_plan* plan, const float* const* W, const float* const* b,
+                           molann_stream_t stream);
+
+/* -- launches --------------------------------------------------------------------------------- */
+
+/* AlignmentLayer.forward ann.py:157-199: out_xyz[N, n_inp, 3] = (x - c(x)) . R(x). */
+int molann_align_f32(const molann_plan* plan, const float* x, int64_t n_frames, float* out_xyz,
+                     molann_stream_t stream);
+
+/* PreprocessingANN.forward ann.py:553-565 (= FeatureLayer.forward ann.py:454-474 when the plan has
+ * no alignment): out[N, feature_dim]. */
+int molann_features_f32(const molann_plan* plan, const float* x, int64_t n_frames, float* out,
+                        molann_stream_t stream);
+
+/* MolANN.forward ann.py:620-624 with the packed copy of the weights: out[N, out_dim]. */
+int molann_forward_packed_f32(const molann_plan* plan, const float* x, int64_t n_frames, float* out,
+                              molann_stream_t stream);
+
+/* MolANN.forward reading the live parameters: molann_plan_update_mlp + molann_forward_packed_f32. */
+int molann_forward_f32(molann_plan* plan, const float* x, int64_t n_frames, const float* const* W,
+                       const float* const* b, float* out, molann_stream_t stream);
+
+/* ann_layers alone on precomputed features f[N, layer_dims[0]] (create_sequential_nn's Sequential,
+ * ann.py:60-65): out[N, out_dim].  Uses the packed weights. */
+int molann_mlp_packed_f32(const molann_plan* plan, const float* f, int64_t n_frames, float* out,
+                          molann_stream_t stream);
+
+/* -- misc ------------------------------------------------------------------------------------- */
+int molann_abi_version(void);
+const char* molann_error_string(int code);
+/* Name + launch geometry of the kernels the last launch on this plan used (for bench / profiles).
+ * Writes a NUL-terminated string of at most `cap` bytes; returns its length. */
+int molann_plan_last_launch_info(const molann_plan* plan, char* buf, int cap);
+
+/* Self-test hooks: the __host__ __device__ math the kernels are built from, compiled for the HOST, so
+ * the CPU test-suite can check it against the oracle without a GPU.  Not a product path. */
+int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9);
+int molann_selftest_feature(int type, int use_angle_value, const float* atoms_xyz, float* out3);
+float molann_selftest_activation(int act, float v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLANN_HIP_H */

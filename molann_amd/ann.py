@@ -1,0 +1,391 @@
+"""`molann.ann`'s module API on the MI355X: same classes, constructor signatures, attributes,
+error behaviour and state_dict keys; `forward` runs hand-written gfx950 kernels through the C ABI
+in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
+
+    AlignmentLayer(align_atom_group, input_atom_group)           ann.py:69-199
+    FeatureMap(feature, input_atom_group, use_angle_value)       ann.py:201-356
+    FeatureLayer(feature_list, input_atom_group, use_angle_value) ann.py:358-474
+    PreprocessingANN(align_layer, feature_layer)                 ann.py:476-565
+    MolANN(preprocessing_layer, ann_layers)                      ann.py:567-624
+    create_sequential_nn(layer_dims, activation)                 ann.py:37-67
+
+There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 tensor that lives
+on a HIP device raises.  Gradients are not implemented on this path yet, so a forward that would
+have to record them raises as well (run it under ``torch.no_grad()``).
+"""
+
+import torch
+import pandas as pd
+
+from . import _capi
+
+_ACT_CODES = (
+    (torch.nn.Tanh, _capi.ACT_TANH, lambda m: True),
+    (torch.nn.ReLU, _capi.ACT_RELU, lambda m: True),
+    (torch.nn.Sigmoid, _capi.ACT_SIGMOID, lambda m: True),
+    (torch.nn.Identity, _capi.ACT_IDENTITY, lambda m: True),
+    (torch.nn.ELU, _capi.ACT_ELU, lambda m: m.alpha == 1.0),
+    (torch.nn.SiLU, _capi.ACT_SILU, lambda m: True),
+    (torch.nn.Softplus, _capi.ACT_SOFTPLUS, lambda m: m.beta == 1.0 and m.threshold == 20.0),
+    (torch.nn.LeakyReLU, _capi.ACT_LEAKY_RELU, lambda m: m.negative_slope == 0.01),
+    (torch.nn.GELU, _capi.ACT_GELU, lambda m: getattr(m, "approximate", "none") == "none"),
+)
+
+
+def create_sequential_nn(layer_dims, activation=torch.nn.Tanh()):
+    """Feed-forward network ``Linear -> act -> ... -> Linear`` (no activation after the last layer).
+
+    Module names follow the reference (`ann.py:63-65`) so that state_dict keys are interchangeable:
+    ``'{i}th_layer'`` and ``'activation of {i}th_layer'``; one activation object is shared.
+    """
+    assert len(layer_dims) >= 2, 'Error: at least 2 layers are needed to define a neural network (length={})!'.format(len(layer_dims))
+    net = torch.nn.Sequential()
+    n_linear = len(layer_dims) - 1
+    for i in range(1, n_linear + 1):
+        net.add_module('%dth_layer' % i, torch.nn.Linear(layer_dims[i - 1], layer_dims[i]))
+        if i < n_linear:
+            net.add_module('activation of %dth_layer' % i, activation)
+    return net
+
+
+def _activation_code(module):
+    for cls, code, ok in _ACT_CODES:
+        if type(module) is cls and ok(module):
+            return code
+    return None
+
+
+def recognise_mlp(ann_layers):
+    """``(linears, activation_code)`` if ``ann_layers`` is a Sequential of the shape
+    `create_sequential_nn` builds with an activation the kernels implement, else ``None``.
+    Walks ``_modules`` (``children()`` de-duplicates the shared activation object)."""
+    if not isinstance(ann_layers, torch.nn.Sequential):
+        return None
+    mods = list(ann_layers._modules.values())
+    if not mods or len(mods) % 2 == 0:
+        return None
+    linears, code = [], None
+    for i, m in enumerate(mods):
+        if i % 2 == 0:
+            if type(m) is not torch.nn.Linear or m.bias is None:
+                return None
+            linears.append(m)
+        else:
+            c = _activation_code(m)
+            if c is None or (code is not None and c != code):
+                return None
+            code = c
+    for a, b in zip(linears[:-1], linears[1:]):
+        if a.out_features != b.in_features:
+            return None
+    if len(linears) > _capi.MAX_LAYERS:
+        return None
+    return linears, (_capi.ACT_IDENTITY if code is None else code)
+
+
+def _local_indices(input_indices, wanted, what):
+    try:
+        return [input_indices.index(int(i)) for i in wanted]
+    except ValueError:
+        raise ValueError(what)
+
+
+def _check_input(x, input_atom_num):
+    assert isinstance(x, torch.Tensor), 'Input x is not a torch tensor'
+    assert x.size(1) == input_atom_num and x.size(2) == 3, \
+        f'Input should be a 3d torch tensor, with sizes [*, {input_atom_num}, 3]. Actual sizes: {x.shape}'
+
+
+def _device_input(x, grad_sources=()):
+    """The tensor the kernels read: float32, on a HIP device, contiguous.  Everything else raises."""
+    if not x.is_cuda:
+        raise RuntimeError("molann_amd runs on the MI355X only: got a %s tensor (no CPU path; move x and the "
+                           "module to a HIP device)" % x.device.type)
+    if x.dtype != torch.float32:
+        raise TypeError("molann_amd kernels are float32; got %s" % x.dtype)
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in grad_sources)):
+        raise NotImplementedError("the HIP forward path does not record gradients yet: call it under "
+                                  "torch.no_grad() (or freeze the parameters)")
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _device_buffer(ref_x, x):
+    """The module's `ref_x` buffer must live where x lives (the reference's matmul, ann.py:187, raises
+    RuntimeError for mixed devices too)."""
+    if ref_x.device != x.device:
+        raise RuntimeError("Expected all tensors to be on the same device: ref_x is on %s, x on %s "
+                           "(move the module with .to(x.device))" % (ref_x.device, x.device))
+    return ref_x
+
+
+class _PlanOwner(object):
+    """Mixin: per-device cache of C-ABI plans, dropped on copy / pickling (plans hold device memory)."""
+
+    def _plans(self):
+        cache = self.__dict__.get("_plan_cache")
+        if cache is None:
+            cache = {}
+            self.__dict__["_plan_cache"] = cache
+        return cache
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_plan_cache", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_plan_cache":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), t._version, t.device.index)
+
+
+class _PlanEntry(object):
+    """A plan plus the versions of the live tensors (ref_x buffer, Linear parameters) packed in it."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.ref_key = None
+        self.mlp_key = None
+
+    def sync_ref(self, ref_x):
+        key = _tensor_key(ref_x)
+        if key != self.ref_key:
+            r = ref_x if (ref_x.dtype == torch.float32 and ref_x.is_contiguous()) else ref_x.float().contiguous()
+            self.plan.update_ref(r)
+            self.ref_key = key
+            self._ref_hold = r
+
+    def sync_mlp(self, linears):
+        key = tuple(_tensor_key(p) for lin in linears for p in (lin.weight, lin.bias))
+        if key != self.mlp_key:
+            ws = [lin.weight.detach().contiguous() for lin in linears]
+            bs = [lin.bias.detach().contiguous() for lin in linears]
+            self.plan.update_mlp(ws, bs)
+            self.mlp_key = key
+
+
+def _feature_spec(feature_layer_or_map):
+    maps = feature_layer_or_map.feature_map_list if isinstance(feature_layer_or_map, FeatureLayer) else [feature_layer_or_map]
+    spec = [(fm.type_id, list(fm._local_atom_indices)) for fm in maps]
+    uav = bool(maps[0].use_angle_value)
+    return spec, uav
+
+
+def _get_entry(owner, x, tag, build):
+    key = (tag, x.device.index)
+    cache = owner._plans()
+    entry = cache.get(key)
+    if entry is None:
+        with torch.cuda.device(x.device):
+            entry = _PlanEntry(build())
+        cache[key] = entry
+    return entry
+
+
+class AlignmentLayer(_PlanOwner, torch.nn.Module):
+    r"""Kabsch superposition of every frame onto the (centred) coordinates of ``align_atom_group``:
+    :math:`x \mapsto (x - c(x)) R(x)`, all ``n_inp`` atoms returned (`ann.py:157-199`)."""
+
+    def __init__(self, align_atom_group, input_atom_group):
+        super(AlignmentLayer, self).__init__()
+        self.align_atom_indices = align_atom_group.ix.tolist()
+        self.input_atom_indices = input_atom_group.ix.tolist()
+        self.input_atom_num = len(input_atom_group)
+        ref_x = torch.from_numpy(align_atom_group.positions)
+        self.register_buffer('ref_x', ref_x)
+        self.ref_x = self.ref_x - torch.mean(self.ref_x, 0)       # centred once (ann.py:140-141)
+        self._local_align_atom_indices = _local_indices(self.input_atom_indices, self.align_atom_indices,
+                                                        "Atoms used for alignment must be among the input")
+
+    def show_info(self):
+        print(f'\n{self.input_atom_num} atoms used for input, (0-based) global indices: \n', self.input_atom_indices)
+        print(f'\n{len(self._local_align_atom_indices)} atoms used for alignment, with (0-based) global indices: \n',
+              self.align_atom_indices)
+        print('local indices\n', self._local_align_atom_indices)
+        print('\ncoordinates of reference state used in aligment:\n', self.ref_x.cpu().numpy())
+
+    def _entry(self, x):
+        entry = _get_entry(self, x, "align", lambda: _capi.Plan(
+            self.input_atom_num, align_idx=self._local_align_atom_indices, ref_x=self.ref_x))
+        entry.sync_ref(_device_buffer(self.ref_x, x))
+        return entry
+
+    def forward(self, x):
+        _check_input(x, self.input_atom_num)
+        x = _device_input(x)
+        out = torch.empty_like(x)
+        if x.shape[0] == 0:
+            return out
+        with torch.cuda.device(x.device):
+            self._entry(x).plan.align(x, out)
+        return out
+
+
+class FeatureMap(_PlanOwner, torch.nn.Module):
+    """One feature (angle / bond / dihedral / position) of every frame (`ann.py:288-356`)."""
+
+    def __init__(self, feature, input_atom_group, use_angle_value=False):
+        super(FeatureMap, self).__init__()
+        self.feature = feature
+        self.type_id = feature.get_type_id()
+        self.use_angle_value = use_angle_value
+        self.input_atom_indices = input_atom_group.ix.tolist()
+        self.input_atom_num = len(input_atom_group)
+        self._local_atom_indices = _local_indices(self.input_atom_indices, feature.get_atom_indices() - 1,
+                                                  "Atoms used in feature must be among the input")
+
+    def dim(self):
+        """1 for angle / bond / dihedral value, 2 for dihedral (cos, sin), 3k for k positions."""
+        if self.type_id in (0, 1):
+            return 1
+        if self.type_id == 2:
+            return 1 if self.use_angle_value == True else 2  # noqa: E712 (mirrors the reference's comparison)
+        if self.type_id == 3:
+            return 3 * len(self.feature.get_atom_indices())
+        return 0
+
+    def forward(self, x):
+        _check_input(x, self.input_atom_num)
+        return _run_features(self, x, None)
+
+
+class FeatureLayer(_PlanOwner, torch.nn.Module):
+    """All features of a list, concatenated column-wise in list order (`ann.py:454-474`)."""
+
+    def __init__(self, feature_list, input_atom_group, use_angle_value=False):
+        super(FeatureLayer, self).__init__()
+        assert len(feature_list) > 0, 'Error: feature list is empty!'
+        self.feature_list = feature_list
+        self.feature_map_list = torch.nn.ModuleList([FeatureMap(f, input_atom_group, use_angle_value) for f in feature_list])
+        self.input_atom_num = len(input_atom_group)
+
+    def get_feature_info(self):
+        return pd.concat([f.get_feature_info() for f in self.feature_list], ignore_index=True)
+
+    def get_feature(self, idx):
+        return self.feature_list[idx]
+
+    def output_dimension(self):
+        return sum([f_map.dim() for f_map in self.feature_map_list])
+
+    def forward(self, x):
+        _check_input(x, self.input_atom_num)
+        return _run_features(self, x, None)
+
+
+def _run_features(feature_owner, x, align_layer, plan_owner=None):
+    """features (optionally of the aligned frame) through one fused launch."""
+    x = _device_input(x)
+    spec, uav = _feature_spec(feature_owner)
+    owner = plan_owner if plan_owner is not None else feature_owner
+
+    def build():
+        if align_layer is None:
+            return _capi.Plan(feature_owner.input_atom_num, features=spec, use_angle_value=uav)
+        return _capi.Plan(feature_owner.input_atom_num, align_idx=align_layer._local_align_atom_indices,
+                          ref_x=align_layer.ref_x, features=spec, use_angle_value=uav)
+
+    entry = _get_entry(owner, x, "features", build)
+    out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float32, device=x.device)
+    if x.shape[0] == 0:
+        return out
+    with torch.cuda.device(x.device):
+        if align_layer is not None:
+            entry.sync_ref(_device_buffer(align_layer.ref_x, x))
+        entry.plan.features(x, out)
+    return out
+
+
+class PreprocessingANN(_PlanOwner, torch.nn.Module):
+    """``feature_layer(align_layer(x))``; ``align_layer=None`` means no alignment (`ann.py:533-565`)."""
+
+    def __init__(self, align_layer, feature_layer):
+        super(PreprocessingANN, self).__init__()
+        self.align_layer = align_layer if align_layer is not None else torch.nn.Identity()
+        self.feature_layer = feature_layer
+
+    def output_dimension(self):
+        return self.feature_layer.output_dimension()
+
+    def _fusable(self):
+        return isinstance(self.feature_layer, FeatureLayer) and \
+            (isinstance(self.align_layer, AlignmentLayer) or type(self.align_layer) is torch.nn.Identity)
+
+    def forward(self, x):
+        if not self._fusable():
+            return self.feature_layer(self.align_layer(x))
+        al = self.align_layer if isinstance(self.align_layer, AlignmentLayer) else None
+        if al is not None:
+            _check_input(x, al.input_atom_num)
+            assert al.input_atom_num == self.feature_layer.input_atom_num, \
+                f'Input should be a 3d torch tensor, with sizes [*, {self.feature_layer.input_atom_num}, 3]. Actual sizes: {x.shape}'
+        _check_input(x, self.feature_layer.input_atom_num)
+        return _run_features(self.feature_layer, x, al, plan_owner=self)
+
+
+class MolANN(_PlanOwner, torch.nn.Module):
+    """``ann_layers(preprocessing_layer(x))`` (`ann.py:606-624`).
+
+    When ``ann_layers`` is a Sequential of Linear layers with one of the supported activations (what
+    `create_sequential_nn` builds) the whole forward is one fused plan; any other module receives the
+    features computed on the GPU.  ``mlp_precision='bf16'`` selects bf16 weights/activations with fp32
+    accumulation on the bf16 MFMA for wide MLPs (the reference has no such mode).
+    """
+
+    def __init__(self, preprocessing_layer, ann_layers, mlp_precision="f32"):
+        super(MolANN, self).__init__()
+        self.preprocessing_layer = preprocessing_layer
+        self.ann_layers = ann_layers
+        assert mlp_precision in ("f32", "bf16")
+        self.mlp_precision = mlp_precision
+
+    def get_preprocessing_layer(self):
+        return self.preprocessing_layer
+
+    def forward(self, x):
+        pp = self.preprocessing_layer
+        rec = recognise_mlp(self.ann_layers)
+        if rec is None or not (isinstance(pp, PreprocessingANN) and pp._fusable()):
+            return self.ann_layers(pp(x))
+        linears, act = rec
+        fl = pp.feature_layer
+        al = pp.align_layer if isinstance(pp.align_layer, AlignmentLayer) else None
+        if al is not None:
+            _check_input(x, al.input_atom_num)
+        _check_input(x, fl.input_atom_num)
+        x = _device_input(x, grad_sources=[p for lin in linears for p in (lin.weight, lin.bias)])
+        spec, uav = _feature_spec(fl)
+        dims = [linears[0].in_features] + [lin.out_features for lin in linears]
+        assert dims[0] == fl.output_dimension(), \
+            'ann_layers expects %d inputs but the feature layer produces %d' % (dims[0], fl.output_dimension())
+
+        def build():
+            return _capi.Plan(fl.input_atom_num,
+                              align_idx=al._local_align_atom_indices if al is not None else None,
+                              ref_x=al.ref_x if al is not None else None,
+                              features=spec, use_angle_value=uav, layer_dims=dims, activation=act,
+                              mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
+
+        entry = _get_entry(self, x, ("forward", tuple(dims), act, self.mlp_precision), build)
+        out = torch.empty((x.shape[0], dims[-1]), dtype=torch.float32, device=x.device)
+        if x.shape[0] == 0:
+            return out
+        for lin in linears:
+            if lin.weight.device != x.device or lin.weight.dtype != torch.float32:
+                raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" %
+                                   (x.device, lin.weight.dtype, lin.weight.device))
+        with torch.cuda.device(x.device):
+            if al is not None:
+                entry.sync_ref(_device_buffer(al.ref_x, x))
+            entry.sync_mlp(linears)
+            entry.plan.forward_packed(x, out)
+        return out

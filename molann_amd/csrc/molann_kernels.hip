@@ -1,0 +1,1189 @@
+// molann_kernels.hip - gfx950 (MI355X / CDNA4) kernels + C ABI for molann's per-frame forward path.
+//
+//   x[N, n_inp, 3] -> AlignmentLayer (Kabsch, ann.py:157-199) -> FeatureLayer (ann.py:454-474)
+//                  -> MLP (create_sequential_nn, ann.py:37-67) -> y[N, d_out]
+//
+// Three kernel families (DESIGN.md has the byte/flop accounting for each):
+//
+//  * frames_lane_kernel   small frames (22-atom class).  One LANE per frame, one wave = a tile of 64
+//    consecutive frames = one contiguous span of HBM, copied to the wave's private LDS region by
+//    LDS-DMA (global_load_lds, 16 B per lane, no VGPRs).  Each lane then reads its atoms from LDS,
+//    solves its own Kabsch rotation, evaluates the feature table and runs the small MLP with the
+//    weights as wave-uniform scalar operands.  No barriers: waves never share data.
+//
+//  * frames_wave_kernel   large frames (5000-atom class).  One WAVE per frame: lanes gather only the
+//    atoms the plan touches, the 3x3 covariance is a wave reduction (DPP), every lane solves the
+//    same rotation, lanes then split the feature table.
+//
+//  * mlp_mfma_kernel      wide MLPs.  One wave per 16-frame row block, activations in the wave's LDS
+//    region, weights streamed from L2 as MFMA B-fragments (fp32-input MFMA 16x16x4, exact fp32; or
+//    bf16 MFMA 16x16x32 with fp32 accumulate).
+//
+// gfx950 only: wave = 64, LDS-DMA, DPP row ops, v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/molann_hip.h"
+#include "molann_math.h"
+
+using namespace molann;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// address-space helpers
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Plan data never changes during a launch: reading it through the constant address space lets the
+// compiler use scalar loads (s_load_dword*) for wave-uniform addresses.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
+    return (const __attribute__((address_space(4))) T*)(p);
+}
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
+}
+
+struct ItemDev { // one expanded feature item, 32 bytes
+    int type;    // ItemType
+    int col;     // first output column
+    int idx[4];  // atom positions inside the n_inp axis (unused entries repeat idx[0])
+    int pad[2];
+};
+
+constexpr int FB_STRIDE = 65; // feature/activation staging [col][FB_STRIDE]: lane-contiguous, odd stride
+constexpr int LANE_MLP_MAX_WIDTH = 32;
+constexpr int LANE_MAX_COLS = 128; // widest feature / output row the lane kernel stages in LDS
+
+// ---------------------------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------------------------
+struct PreArgs {
+    long n_frames;
+    int n_inp;
+    int frame_dw;     // 3 * n_inp
+    int mode;         // 0: features (+ fused MLP)   1: aligned coordinates
+    int n_align;
+    int n_items;
+    int out_cols;     // columns written per frame in mode 0
+    int step_f;       // 64 / out_cols
+    int step_c;       // 64 % out_cols
+    int lds_per_wave; // bytes (lane kernel)
+    int fbuf_off;     // byte offset of the staging buffer inside the wave's region
+    int x_wide;       // x is 16-byte aligned
+    int out_wide;     // out is 16-byte aligned
+    int n_layers;     // fused MLP (lane kernel only); 0 = none
+    int act;
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int woff[MOLANN_MAX_LAYERS]; // float offset of layer l inside wpack: bias[W], then W[k][W]
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave reduction (sum over the 64 lanes, result broadcast) with DPP row operations
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                                 BANK_MASK, BOUND));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v); // row_half_mirror
+    v += dpp_mov<0x140>(v); // row_mirror       -> every lane holds its row's (16-lane) sum
+    v += dpp_mov<0x142, 0xa>(v); // row_bcast15 : lane 15 -> row 1, lane 47 -> row 3
+    v += dpp_mov<0x143, 0xc>(v); // row_bcast31 : lane 31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    // same butterfly on the two 32-bit halves of each partner value
+    auto step = [](double x, auto mover) {
+        const long long b = __builtin_bit_cast(long long, x);
+        const int lo = mover((int)(b & 0xffffffffll)), hi = mover((int)(b >> 32));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    };
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true); });
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0x4E, 0xf, 0xf, true); });
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0x141, 0xf, 0xf, true); });
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0x140, 0xf, 0xf, true); });
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0x142, 0xa, 0xf, true); });
+    v += step(v, [](int w) { return __builtin_amdgcn_update_dpp(0, w, 0x143, 0xc, 0xf, true); });
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// activation over a register array (switch hoisted out of the unrolled loop)
+// ---------------------------------------------------------------------------------------------
+// CHEAP: only the activations that are a handful of instructions (the lane kernel unrolls this over
+// up to 32 registers; ELU / Softplus / GELU pull in libm-sized code and go through the MFMA MLP kernel).
+template <int W, bool CHEAP>
+__device__ __forceinline__ void activate(int act, float (&h)[W]) {
+    switch (act) {
+    case MOLANN_ACT_TANH:
+#pragma unroll
+        for (int j = 0; j < W; ++j) h[j] = act_tanh(h[j]);
+        break;
+    case MOLANN_ACT_RELU:
+#pragma unroll
+        for (int j = 0; j < W; ++j) h[j] = apply_activation(MOLANN_ACT_RELU, h[j]);
+        break;
+    case MOLANN_ACT_SIGMOID:
+#pragma unroll
+        for (int j = 0; j < W; ++j) h[j] = act_sigmoid(h[j]);
+        break;
+    case MOLANN_ACT_SILU:
+#pragma unroll
+        for (int j = 0; j < W; ++j) h[j] = h[j] * act_sigmoid(h[j]);
+        break;
+    case MOLANN_ACT_LEAKY_RELU:
+#pragma unroll
+        for (int j = 0; j < W; ++j) h[j] = apply_activation(MOLANN_ACT_LEAKY_RELU, h[j]);
+        break;
+    case MOLANN_ACT_IDENTITY:
+        break;
+    default:
+        if constexpr (!CHEAP) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) h[j] = apply_activation(act, h[j]);
+        }
+        break;
+    }
+}
+
+// =============================================================================================
+// frames_lane_kernel: one lane per frame, 64-frame tiles staged through LDS by LDS-DMA
+// =============================================================================================
+template <int MLPW>
+__global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          const int* __restrict__ align_idx_g,
+                                                          const float* __restrict__ ref_g,    // [a*3] + consts
+                                                          const double* __restrict__ ref64_g, // same, fp64
+                                                          const ItemDev* __restrict__ items_g,
+                                                          const float* __restrict__ wpack_g, PreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    unsigned char* wreg = smem + (size_t)wave * a.lds_per_wave;
+    float* tile = (float*)wreg;
+    float* fbuf = (float*)(wreg + a.fbuf_off);
+
+    const auto align_idx = as_const(align_idx_g);
+    const auto ref = as_const(ref_g);
+    const auto ref64 = as_const(ref64_g);
+    const auto items = as_const((const int*)items_g);
+    const auto wpack = as_const(wpack_g);
+
+    const long n_tiles = (a.n_frames + 63) >> 6;
+    const int frame_bytes = a.frame_dw * 4;
+    const long tile_bytes = (long)frame_bytes * 64;
+
+    // read-out position of this lane: element e = it*64 + lane of the [64][out_cols] tile
+    int ro_f0 = 0, ro_c0 = 0;
+    if (a.mode == 0) {
+        ro_f0 = lane / a.out_cols;
+        ro_c0 = lane - ro_f0 * a.out_cols;
+    }
+
+    for (long t = (long)blockIdx.x * wpb + wave; t < n_tiles; t += (long)gridDim.x * wpb) {
+        const long rem = a.n_frames - t * 64;
+        const int nfr = rem < 64 ? (int)rem : 64;
+        const int valid_bytes = nfr * frame_bytes;
+        const unsigned char* gsrc = (const unsigned char*)x + t * tile_bytes;
+
+        // ---- 1. HBM -> LDS, whole frames, contiguous ------------------------------------------
+        if (a.x_wide) {
+            const int nchunk = valid_bytes >> 4;
+            for (int c0 = 0; c0 < nchunk; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < nchunk) glds16(gsrc + (size_t)c * 16, (unsigned char*)tile + (size_t)c0 * 16);
+            }
+            const int rem_dw = (valid_bytes & 15) >> 2;
+            if (lane < rem_dw) glds4(gsrc + (size_t)nchunk * 16 + lane * 4, (unsigned char*)tile + (size_t)nchunk * 16);
+        } else {
+            const int ndw = valid_bytes >> 2;
+            for (int c0 = 0; c0 < ndw; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < ndw) glds4(gsrc + (size_t)c * 4, (unsigned char*)tile + (size_t)c0 * 4);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // lanes past the end of the batch recompute the last valid frame (their stores are masked)
+        const int fl = lane < nfr ? lane : nfr - 1;
+        const float* fr = tile + fl * a.frame_dw;
+
+        // ---- 2. Kabsch (ann.py:179-195) --------------------------------------------------------
+        float R[9];
+        V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        const bool has_align = a.n_align > 0;
+        if (has_align) {
+            const int k0 = align_idx[0];
+            c0 = v3(fr[3 * k0], fr[3 * k0 + 1], fr[3 * k0 + 2]); // provisional centre: first align atom
+            float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
+            double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            for (int i = 0; i < a.n_align; ++i) {
+                const int k = align_idx[i];
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3 p = v3(fr[3 * k], fr[3 * k + 1], fr[3 * k + 2]) - c0;
+                sx += p.x; sy += p.y; sz += p.z;
+                g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
+                const double px = p.x, py = p.y, pz = p.z;
+                h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
+                h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
+                h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            }
+            // constants after the reference coordinates: sum ref (3), sum |ref|^2, 1/a, a
+            const int cb = 3 * a.n_align;
+            const double srx = ref64[cb], sry = ref64[cb + 1], srz = ref64[cb + 2], gref = ref64[cb + 3];
+            const float inv_a = ref[cb + 4], fa = ref[cb + 5];
+            dl = v3(sx * inv_a, sy * inv_a, sz * inv_a); // centroid = c0 + dl (ann.py:181)
+            // H = sum (p - dl) ref^T = sum p ref^T - dl (sum ref)^T   (ann.py:183-187)
+            const double dx = dl.x, dy = dl.y, dz = dl.z;
+            h[0] = fma(-dx, srx, h[0]); h[1] = fma(-dx, sry, h[1]); h[2] = fma(-dx, srz, h[2]);
+            h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
+            h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
+            const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+        }
+
+        if (a.mode == 1) {
+            // ---- 3a. AlignmentLayer.forward: every atom, in place, then LDS -> HBM ------------
+            float* frw = tile + fl * a.frame_dw;
+            for (int k = 0; k < a.n_inp; ++k) {
+                const V3 p = (v3(frw[3 * k], frw[3 * k + 1], frw[3 * k + 2]) - c0) - dl;
+                const V3 y = rotate(p, R); // ann.py:197
+                if (lane < nfr) {
+                    frw[3 * k] = y.x; frw[3 * k + 1] = y.y; frw[3 * k + 2] = y.z;
+                }
+            }
+            unsigned char* gdst = (unsigned char*)out + t * tile_bytes;
+            if (a.out_wide) {
+                const int nchunk = valid_bytes >> 4;
+                for (int c = lane; c < nchunk; c += 64) ((float4*)gdst)[c] = ((const float4*)tile)[c];
+                const int done_dw = nchunk << 2, ndw = valid_bytes >> 2;
+                if (done_dw + lane < ndw) ((float*)gdst)[done_dw + lane] = tile[done_dw + lane];
+            } else {
+                const int ndw = valid_bytes >> 2;
+                for (int c = lane; c < ndw; c += 64) ((float*)gdst)[c] = tile[c];
+            }
+            continue;
+        }
+
+        // ---- 3b. feature table (ann.py:323-354, 473) -> fbuf[col][lane] -----------------------
+        for (int it = 0; it < a.n_items; ++it) {
+            const int type = items[8 * it], col = items[8 * it + 1];
+            const int i0 = items[8 * it + 2], i1 = items[8 * it + 3], i2 = items[8 * it + 4], i3 = items[8 * it + 5];
+            V3 p0 = v3(fr[3 * i0], fr[3 * i0 + 1], fr[3 * i0 + 2]);
+            V3 p1 = p0, p2 = p0, p3 = p0;
+            if (type != IT_POSITION) {
+                p1 = v3(fr[3 * i1], fr[3 * i1 + 1], fr[3 * i1 + 2]);
+                if (type != IT_BOND) {
+                    p2 = v3(fr[3 * i2], fr[3 * i2 + 1], fr[3 * i2 + 2]);
+                    if (type == IT_DIHEDRAL_CS || type == IT_DIHEDRAL_VAL) p3 = v3(fr[3 * i3], fr[3 * i3 + 1], fr[3 * i3 + 2]);
+                }
+            }
+            if (has_align) { // features see the ALIGNED frame (ann.py:565)
+                p0 = rotate((p0 - c0) - dl, R);
+                if (type != IT_POSITION) {
+                    p1 = rotate((p1 - c0) - dl, R);
+                    p2 = rotate((p2 - c0) - dl, R);
+                    p3 = rotate((p3 - c0) - dl, R);
+                }
+            }
+            float v[3];
+            const int w = eval_item(type, p0, p1, p2, p3, v);
+            fbuf[col * FB_STRIDE + lane] = v[0];
+            if (w > 1) fbuf[(col + 1) * FB_STRIDE + lane] = v[1];
+            if (w > 2) fbuf[(col + 2) * FB_STRIDE + lane] = v[2];
+        }
+
+        // ---- 4. fused small MLP (ann.py:60-65): weights are wave-uniform scalar operands ------
+        if constexpr (MLPW > 0) {
+            float h[MLPW];
+            {
+                const auto wl = wpack + a.woff[0];
+#pragma unroll
+                for (int j = 0; j < MLPW; ++j) h[j] = wl[j];
+                const int K = a.dims[0];
+                for (int k = 0; k < K; ++k) {
+                    const float f = fbuf[k * FB_STRIDE + lane];
+                    const auto wr = wl + MLPW + k * MLPW;
+#pragma unroll
+                    for (int j = 0; j < MLPW; ++j) h[j] = fmaf(wr[j], f, h[j]);
+                }
+            }
+            for (int l = 1; l < a.n_layers; ++l) {
+                activate<MLPW, true>(a.act, h);
+                float g[MLPW];
+                const auto wl = wpack + a.woff[l];
+#pragma unroll
+                for (int j = 0; j < MLPW; ++j) g[j] = wl[j];
+                const int K = a.dims[l];
+#pragma unroll
+                for (int k = 0; k < MLPW; ++k) {
+                    if (k < K) {
+                        const auto wr = wl + MLPW + k * MLPW;
+#pragma unroll
+                        for (int j = 0; j < MLPW; ++j) g[j] = fmaf(wr[j], h[k], g[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MLPW; ++j) h[j] = g[j];
+            }
+#pragma unroll
+            for (int j = 0; j < MLPW; ++j)
+                if (j < a.out_cols) fbuf[j * FB_STRIDE + lane] = h[j];
+        }
+
+        // ---- 5. read-out: fbuf[col][frame] -> out[t*64 + frame][col], contiguous per wave ------
+        {
+            float* gdst = out + t * 64 * (long)a.out_cols;
+            const int n_valid = nfr * a.out_cols;
+            int f = ro_f0, c = ro_c0;
+            for (int e = lane; e < n_valid; e += 64) {
+                gdst[e] = fbuf[c * FB_STRIDE + f];
+                c += a.step_c;
+                f += a.step_f;
+                if (c >= a.out_cols) { c -= a.out_cols; ++f; }
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// frames_wave_kernel: one wave per frame, atoms gathered from HBM
+// =============================================================================================
+__device__ __forceinline__ V3 load_atom(const float* __restrict__ xf, int k) {
+    return v3(xf[3 * k], xf[3 * k + 1], xf[3 * k + 2]);
+}
+
+__global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          const int* __restrict__ align_idx,
+                                                          const float* __restrict__ ref,
+                                                          const double* __restrict__ ref64,
+                                                          const ItemDev* __restrict__ items, PreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const auto refc = as_const(ref);
+    const bool has_align = a.n_align > 0;
+
+    for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
+        const float* xf = x + f * (long)a.frame_dw;
+        float R[9];
+        V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        if (has_align) {
+            const int k0 = as_const(align_idx)[0];
+            c0 = load_atom(xf, k0);
+            float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
+            double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+#pragma unroll 4
+            for (int i = lane; i < a.n_align; i += 64) {
+                const int k = align_idx[i];
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3 p = load_atom(xf, k) - c0;
+                sx += p.x; sy += p.y; sz += p.z;
+                g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
+                const double px = p.x, py = p.y, pz = p.z;
+                h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
+                h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
+                h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            }
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            const int cb = 3 * a.n_align;
+            const auto r64c = as_const(ref64);
+            const double srx = r64c[cb], sry = r64c[cb + 1], srz = r64c[cb + 2], gref = r64c[cb + 3];
+            const float inv_a = refc[cb + 4], fa = refc[cb + 5];
+            dl = v3(sx * inv_a, sy * inv_a, sz * inv_a);
+            const double dx = dl.x, dy = dl.y, dz = dl.z;
+            h[0] = fma(-dx, srx, h[0]); h[1] = fma(-dx, sry, h[1]); h[2] = fma(-dx, srz, h[2]);
+            h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
+            h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
+            const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+        }
+
+        if (a.mode == 1) { // AlignmentLayer.forward: all atoms, coalesced 12 B per lane
+            float* of = out + f * (long)a.frame_dw;
+#pragma unroll 4
+            for (int k = lane; k < a.n_inp; k += 64) {
+                const V3 y = rotate((load_atom(xf, k) - c0) - dl, R);
+                of[3 * k] = y.x; of[3 * k + 1] = y.y; of[3 * k + 2] = y.z;
+            }
+            continue;
+        }
+
+        float* of = out + f * (long)a.out_cols;
+#pragma unroll 2
+        for (int it = lane; it < a.n_items; it += 64) {
+            const int4 d0 = ((const int4*)items)[2 * it];
+            const int2 d1 = ((const int2*)items)[4 * it + 2];
+            const int type = d0.x, col = d0.y, i0 = d0.z, i1 = d0.w, i2 = d1.x, i3 = d1.y;
+            V3 p0 = load_atom(xf, i0), p1 = load_atom(xf, i1), p2 = load_atom(xf, i2), p3 = load_atom(xf, i3);
+            if (has_align) {
+                p0 = rotate((p0 - c0) - dl, R);
+                p1 = rotate((p1 - c0) - dl, R);
+                p2 = rotate((p2 - c0) - dl, R);
+                p3 = rotate((p3 - c0) - dl, R);
+            }
+            float v[3];
+            const int w = eval_item(type, p0, p1, p2, p3, v);
+            of[col] = v[0];
+            if (w > 1) of[col + 1] = v[1];
+            if (w > 2) of[col + 2] = v[2];
+        }
+    }
+}
+
+// =============================================================================================
+// mlp_mfma_kernel: wide MLP over precomputed features, one wave per 16-frame row block
+// =============================================================================================
+// Packed weights, layer l (fp32 path): Wp[Jp][Kp] row-major (torch.nn.Linear layout, zero padded to
+// Jp = ceil16(J), Kp = ceil16(K)), then bias[Jp].  v_mfma_f32_16x16x4_f32 wants, per k-step, lane l
+// to hold A[row l&15][k = l>>4] and B[k = l>>4][col l&15]; the k order inside a 16-wide group is
+// free as long as A and B agree, so lane quad q = l>>4 takes the 4 CONTIGUOUS k's 4q..4q+3 of the
+// group (one 16-byte load each for A from LDS and B from the weight row) and feeds them to 4 MFMAs.
+struct MlpArgs {
+    long n_frames;
+    int n_layers;
+    int act;
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int kp[MOLANN_MAX_LAYERS];    // padded K per layer
+    int jp[MOLANN_MAX_LAYERS];    // padded J per layer
+    long woff[MOLANN_MAX_LAYERS]; // element offset of layer l in the packed buffer
+    int ld;                       // LDS row stride (elements) of both activation buffers
+    int lds_per_wave;             // bytes
+    int in_stride;                // row stride of the input features (floats)
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f2bf(float f) { // round-to-nearest-even, NaN kept
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void mlp_mfma_kernel(const float* __restrict__ feat, float* __restrict__ out,
+                                                       const void* __restrict__ wpack_v, MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
+    constexpr int KG = BF16 ? 32 : 16; // k's consumed per group (bf16: one MFMA; f32: four MFMAs)
+    constexpr int KQ = BF16 ? 8 : 4;   // contiguous k's per lane quad
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    elem_t* bufA = (elem_t*)(smem + (size_t)wave * a.lds_per_wave);
+    elem_t* bufB = bufA + 16 * a.ld;
+    const elem_t* wpack = (const elem_t*)wpack_v;
+    const long n_blocks = (a.n_frames + 15) >> 4;
+
+    for (long rb = (long)blockIdx.x * wpb + wave; rb < n_blocks; rb += (long)gridDim.x * wpb) {
+        const long frame0 = rb << 4;
+        const long remf = a.n_frames - frame0;
+        const int nrow = remf < 16 ? (int)remf : 16;
+        // ---- stage the 16 input rows into LDS (zero padded to kp[0]) -------------------------
+        {
+            const int K0 = a.dims[0], Kp0 = a.kp[0];
+            for (int r = 0; r < 16; ++r) {
+                const float* src = feat + (frame0 + (r < nrow ? r : nrow - 1)) * (long)a.in_stride;
+                for (int k = lane; k < Kp0; k += 64) {
+                    const float v = k < K0 ? src[k] : 0.f;
+                    if constexpr (BF16) bufA[r * a.ld + k] = f2bf(v);
+                    else bufA[r * a.ld + k] = v;
+                }
+            }
+        }
+        elem_t* cur = bufA;
+        elem_t* nxt = bufB;
+        for (int l = 0; l < a.n_layers; ++l) {
+            const int Kp = a.kp[l], Jp = a.jp[l], J = a.dims[l + 1];
+            const elem_t* W = wpack + a.woff[l];
+            const float* bias = (const float*)(W + (long)Jp * Kp);
+            const bool last = (l + 1 == a.n_layers);
+            for (int n0 = 0; n0 < Jp; n0 += 16) {
+                const float bj = bias[n0 + r16];
+                f32x4 acc = {bj, bj, bj, bj}; // C[row 4q+reg][col r16]: bias depends on the column only
+                const elem_t* wrow = W + (long)(n0 + r16) * Kp + q * KQ;
+                const elem_t* arow = cur + r16 * a.ld + q * KQ;
+#pragma unroll 2
+                for (int kg = 0; kg < Kp; kg += KG) {
+                    if constexpr (BF16) {
+                        const bf16x8 bv = *(const bf16x8*)(wrow + kg);
+                        const bf16x8 av = *(const bf16x8*)(arow + kg);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+                    } else {
+                        const f32x4 bv = *(const f32x4*)(wrow + kg);
+                        const f32x4 av = *(const f32x4*)(arow + kg);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc, 0, 0, 0);
+                    }
+                }
+                const int col = n0 + r16;
+                if (last) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * q + r;
+                        if (row < nrow && col < J) out[(frame0 + row) * (long)J + col] = acc[r];
+                    }
+                } else {
+                    float h[4] = {acc[0], acc[1], acc[2], acc[3]};
+                    activate<4, false>(a.act, h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = col < J ? h[r] : 0.f; // padded columns feed zero into the next layer
+                        if constexpr (BF16) nxt[(4 * q + r) * a.ld + col] = f2bf(v);
+                        else nxt[(4 * q + r) * a.ld + col] = v;
+                    }
+                }
+            }
+            if (!last) { // zero the k padding of the next layer beyond Jp (kp[l+1] may exceed Jp)
+                const int Kn = a.kp[l + 1];
+                for (int k = Jp + lane; k < Kn; k += 64)
+                    for (int r = 0; r < 16; ++r) nxt[r * a.ld + k] = (elem_t)0;
+            }
+            elem_t* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    }
+}
+
+// =============================================================================================
+// pack kernels (live parameters -> plan-owned padded copies)
+// =============================================================================================
+struct PackArgs {
+    const float* W[MOLANN_MAX_LAYERS];
+    const float* b[MOLANN_MAX_LAYERS];
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int n_layers;
+    // lane-kernel layout
+    int mlpw;
+    int woff[MOLANN_MAX_LAYERS];
+    // mfma layout
+    int kp[MOLANN_MAX_LAYERS];
+    int jp[MOLANN_MAX_LAYERS];
+    long moff[MOLANN_MAX_LAYERS];
+    int bf16;
+};
+
+// lane layout, layer l: bias[mlpw] then Wt[k][mlpw]  (transposed, zero padded)
+__global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
+    const int l = blockIdx.y;
+    const int K = p.dims[l], J = p.dims[l + 1], W = p.mlpw;
+    float* d = dst + p.woff[l];
+    const int total = W + K * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        if (e < W) {
+            d[e] = e < J ? p.b[l][e] : 0.f;
+        } else {
+            const int k = (e - W) / W, j = (e - W) - k * W;
+            d[e] = j < J ? p.W[l][(long)j * K + k] : 0.f;
+        }
+    }
+}
+
+// mfma layout, layer l: Wp[Jp][Kp] (zero padded; fp32 or bf16) then bias[Jp] (fp32)
+__global__ void pack_mfma_kernel(void* __restrict__ dst_v, PackArgs p) {
+    const int l = blockIdx.y;
+    const int K = p.dims[l], J = p.dims[l + 1], Kp = p.kp[l], Jp = p.jp[l];
+    const long nW = (long)Jp * Kp;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nW + Jp; e += (long)gridDim.x * blockDim.x) {
+        if (e < nW) {
+            const int j = (int)(e / Kp), k = (int)(e - (long)j * Kp);
+            const float v = (j < J && k < K) ? p.W[l][(long)j * K + k] : 0.f;
+            if (p.bf16) ((unsigned short*)dst_v)[p.moff[l] + e] = f2bf(v);
+            else ((float*)dst_v)[p.moff[l] + e] = v;
+        } else {
+            const int j = (int)(e - nW);
+            const float v = j < J ? p.b[l][j] : 0.f;
+            if (p.bf16) ((float*)((unsigned short*)dst_v + p.moff[l] + nW))[j] = v;
+            else ((float*)dst_v)[p.moff[l] + nW + j] = v;
+        }
+    }
+}
+
+// ref_x (device, centred) -> plan copy + the constants the kernels need after it
+__global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ dst64, const float* __restrict__ ref,
+                                int n_align) {
+    if (blockIdx.x != 0) return;
+    __shared__ double red[4][256];
+    double s[4] = {0., 0., 0., 0.};
+    for (int i = threadIdx.x; i < n_align; i += blockDim.x) {
+        const float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+        dst[3 * i] = rx; dst[3 * i + 1] = ry; dst[3 * i + 2] = rz;
+        dst64[3 * i] = rx; dst64[3 * i + 1] = ry; dst64[3 * i + 2] = rz;
+        s[0] += rx; s[1] += ry; s[2] += rz;
+        s[3] += (double)rx * rx + (double)ry * ry + (double)rz * rz;
+    }
+    for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int w = blockDim.x >> 1; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* c = dst + 3 * n_align;
+        double* c64 = dst64 + 3 * n_align;
+        for (int k = 0; k < 4; ++k) { c[k] = (float)red[k][0]; c64[k] = red[k][0]; }
+        c[4] = 1.0f / (float)n_align;
+        c[5] = (float)n_align;
+        c64[4] = 1.0 / (double)n_align;
+        c64[5] = (double)n_align;
+    }
+}
+
+inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+} // namespace
+
+// =============================================================================================
+// plan
+// =============================================================================================
+struct molann_plan {
+    int device;
+    int num_cus;
+    int n_inp, n_align, n_features, n_items, d_feat, use_angle_value;
+    int n_layers, act, mlp_prec;
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int out_dim;
+    int family;        // 0 lane-per-frame, 1 wave-per-frame
+    bool fused_mlp;    // lane kernel runs the MLP itself
+    int mlpw;          // register width of the fused MLP (8/16/32)
+    // device memory (one allocation)
+    unsigned char* blob;
+    int* d_align_idx;
+    float* d_ref;      // [3a] + 6 constants
+    double* d_ref64;   // the same in fp64 (covariance accumulation)
+    ItemDev* d_items;
+    float* d_wlane;    // fused layout
+    void* d_wmfma;     // mfma layout
+    float* d_work;     // feature chunk [work_frames][d_feat]
+    long work_frames;
+    int woff[MOLANN_MAX_LAYERS];
+    int kp[MOLANN_MAX_LAYERS], jp[MOLANN_MAX_LAYERS];
+    long moff[MOLANN_MAX_LAYERS];
+    int mlp_ld, mlp_lds_per_wave;
+    // lane kernel geometry
+    int lane_lds_per_wave, lane_fbuf_off, lane_wpb;
+    bool mlp_packed;
+    char last_info[256];
+};
+
+namespace {
+
+#define HIP_TRY(expr)                      \
+    do {                                   \
+        hipError_t _e = (expr);            \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+int lane_geometry(molann_plan* p, int cols_needed) {
+    const int tile_bytes = 64 * p->n_inp * 12;
+    const int tile_pad = ceil_to(tile_bytes, 16);
+    const int fbuf_bytes = ceil_to(cols_needed * FB_STRIDE * 4, 16);
+    p->lane_fbuf_off = tile_pad;
+    p->lane_lds_per_wave = tile_pad + fbuf_bytes;
+    // waves never share LDS, so the block size is free: take the one that packs most waves into the
+    // CU's 160 KiB (blocks <= 64 KiB: the LDS-DMA destination offset is 16 bits), larger block on ties
+    const long L = p->lane_lds_per_wave;
+    int best = 0, best_waves = 0;
+    for (int wpb = 4; wpb >= 1; --wpb) {
+        if (wpb * L > 65536) continue;
+        long waves = wpb * (163840 / (wpb * L));
+        if (waves > 32) waves = 32;
+        if (waves > best_waves) { best_waves = (int)waves; best = wpb; }
+    }
+    p->lane_wpb = best;
+    return (best >= 1 && best_waves >= 4) ? 0 : -1; // fewer than 4 waves per CU: use the wave-per-frame kernel
+}
+
+int validate_desc(const molann_plan_desc* d) {
+    if (!d) return MOLANN_E_NULL;
+    if (d->abi_version != MOLANN_ABI_VERSION) return MOLANN_E_DESC;
+    if (d->n_inp <= 0 || d->n_align < 0 || d->n_features < 0 || d->n_layers < 0) return MOLANN_E_DESC;
+    if (d->n_layers > MOLANN_MAX_LAYERS) return MOLANN_E_UNSUPPORTED;
+    if (d->n_align == 0 && d->n_features == 0 && d->n_layers == 0) return MOLANN_E_DESC;
+    if (d->n_align > 0) {
+        if (!d->align_idx || !d->ref_x) return MOLANN_E_NULL;
+        for (int i = 0; i < d->n_align; ++i)
+            if (d->align_idx[i] < 0 || d->align_idx[i] >= d->n_inp) return MOLANN_E_INDEX;
+    }
+    if (d->n_features > 0) {
+        if (!d->feat_type || !d->feat_ptr || !d->feat_idx) return MOLANN_E_NULL;
+        if (d->feat_ptr[0] != 0) return MOLANN_E_DESC;
+        for (int f = 0; f < d->n_features; ++f) {
+            const int cnt = d->feat_ptr[f + 1] - d->feat_ptr[f];
+            const int t = d->feat_type[f];
+            if (cnt < 0) return MOLANN_E_DESC;
+            if (t == MOLANN_FEAT_ANGLE) { if (cnt != 3) return MOLANN_E_FEATURE; }   // feature.py:88
+            else if (t == MOLANN_FEAT_BOND) { if (cnt != 2) return MOLANN_E_FEATURE; }   // feature.py:91
+            else if (t == MOLANN_FEAT_DIHEDRAL) { if (cnt != 4) return MOLANN_E_FEATURE; } // feature.py:94
+            else if (t == MOLANN_FEAT_POSITION) { if (cnt < 1) return MOLANN_E_FEATURE; }
+            else return MOLANN_E_FEATURE;                                                  // feature.py:82
+            for (int i = d->feat_ptr[f]; i < d->feat_ptr[f + 1]; ++i)
+                if (d->feat_idx[i] < 0 || d->feat_idx[i] >= d->n_inp) return MOLANN_E_INDEX;
+        }
+    }
+    if (d->n_layers > 0) {
+        if (!d->layer_dims) return MOLANN_E_NULL;
+        for (int i = 0; i <= d->n_layers; ++i)
+            if (d->layer_dims[i] <= 0) return MOLANN_E_DESC;
+        if (d->activation < 0 || d->activation > MOLANN_ACT_GELU) return MOLANN_E_UNSUPPORTED;
+        if (d->mlp_precision != MOLANN_MLP_F32 && d->mlp_precision != MOLANN_MLP_BF16) return MOLANN_E_UNSUPPORTED;
+    }
+    return MOLANN_OK;
+}
+
+int grid_for(const molann_plan* p, long work_items, int items_per_block, int blocks_per_cu) {
+    long need = (work_items + items_per_block - 1) / items_per_block;
+    long cap = (long)p->num_cus * blocks_per_cu;
+    long g = need < cap ? need : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+void fill_pre_args(const molann_plan* p, PreArgs& a, long n_frames, int mode, int out_cols, bool with_mlp,
+                   const void* x, const void* out) {
+    memset(&a, 0, sizeof(a));
+    a.n_frames = n_frames;
+    a.n_inp = p->n_inp;
+    a.frame_dw = 3 * p->n_inp;
+    a.mode = mode;
+    a.n_align = p->n_align;
+    a.n_items = p->n_items;
+    a.out_cols = out_cols > 0 ? out_cols : 1;
+    a.step_f = 64 / a.out_cols;
+    a.step_c = 64 % a.out_cols;
+    a.lds_per_wave = p->lane_lds_per_wave;
+    a.fbuf_off = p->lane_fbuf_off;
+    a.x_wide = (((uintptr_t)x) & 15) == 0;
+    a.out_wide = (((uintptr_t)out) & 15) == 0;
+    a.n_layers = with_mlp ? p->n_layers : 0;
+    a.act = p->act;
+    for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
+    for (int i = 0; i < p->n_layers; ++i) a.woff[i] = p->woff[i];
+}
+
+// preprocessing (align / features / fused forward) for n_frames starting at x -> out
+int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mode, bool with_mlp,
+               hipStream_t stream) {
+    const int out_cols = mode == 1 ? 0 : (with_mlp ? p->out_dim : p->d_feat);
+    PreArgs a;
+    fill_pre_args(p, a, n_frames, mode, out_cols, with_mlp, x, out);
+    if (p->family == 0) {
+        const int wpb = p->lane_wpb;
+        const long n_tiles = (n_frames + 63) / 64;
+        int bpc = (int)(163840 / ((long)wpb * p->lane_lds_per_wave));
+        if (bpc < 1) bpc = 1;
+        if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
+        const int grid = grid_for(p, n_tiles, wpb, bpc);
+        const size_t lds = (size_t)wpb * p->lane_lds_per_wave;
+        const dim3 block(64 * wpb);
+        const int w = with_mlp ? p->mlpw : 0;
+#define LAUNCH_LANE(W)                                                                                          \
+    hipLaunchKernelGGL((frames_lane_kernel<W>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
+                       p->d_ref64, p->d_items, p->d_wlane, a)
+        if (w == 0) LAUNCH_LANE(0);
+        else if (w == 8) LAUNCH_LANE(8);
+        else if (w == 16) LAUNCH_LANE(16);
+        else LAUNCH_LANE(32);
+#undef LAUNCH_LANE
+        snprintf(p->last_info, sizeof(p->last_info), "frames_lane_kernel<%d> grid=%d block=%d lds=%zu mode=%d", w, grid,
+                 64 * wpb, lds, mode);
+    } else {
+        const int wpb = 4;
+        const int grid = grid_for(p, n_frames, wpb, 8);
+        hipLaunchKernelGGL(frames_wave_kernel, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref,
+                           p->d_ref64, p->d_items, a);
+        snprintf(p->last_info, sizeof(p->last_info), "frames_wave_kernel grid=%d block=%d mode=%d", grid, 64 * wpb, mode);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, float* out, hipStream_t stream) {
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_frames = n_frames;
+    a.n_layers = p->n_layers;
+    a.act = p->act;
+    for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
+    for (int i = 0; i < p->n_layers; ++i) { a.kp[i] = p->kp[i]; a.jp[i] = p->jp[i]; a.woff[i] = p->moff[i]; }
+    a.ld = p->mlp_ld;
+    a.lds_per_wave = p->mlp_lds_per_wave;
+    a.in_stride = in_stride;
+    int wpb = 65536 / p->mlp_lds_per_wave;
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) wpb = 1; // one wave with up to 160 KiB (attribute raised at plan creation)
+    int bpc = (int)(163840 / ((long)wpb * p->mlp_lds_per_wave));
+    if (bpc < 1) bpc = 1;
+    if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
+    const long n_blocks = (n_frames + 15) / 16;
+    const int grid = grid_for(p, n_blocks, wpb, bpc);
+    const size_t lds = (size_t)wpb * p->mlp_lds_per_wave;
+    if (p->mlp_prec == MOLANN_MLP_BF16)
+        hipLaunchKernelGGL((mlp_mfma_kernel<true>), dim3(grid), dim3(64 * wpb), lds, stream, feat, out, p->d_wmfma, a);
+    else
+        hipLaunchKernelGGL((mlp_mfma_kernel<false>), dim3(grid), dim3(64 * wpb), lds, stream, feat, out, p->d_wmfma, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int molann_abi_version(void) { return MOLANN_ABI_VERSION; }
+
+const char* molann_error_string(int code) {
+    switch (code) {
+    case MOLANN_OK: return "ok";
+    case MOLANN_E_NULL: return "required pointer is NULL";
+    case MOLANN_E_DESC: return "inconsistent plan description";
+    case MOLANN_E_INDEX: return "atom index outside [0, n_inp)";
+    case MOLANN_E_FEATURE: return "unknown feature type or wrong atom count for its type";
+    case MOLANN_E_STAGE: return "plan lacks the stage this call needs";
+    case MOLANN_E_ALIGNMENT: return "pointer is not 4-byte aligned";
+    case MOLANN_E_UNSUPPORTED: return "shape not covered by the gfx950 kernels";
+    case MOLANN_E_NOT_PACKED: return "MLP weights were never packed (call molann_plan_update_mlp)";
+    case MOLANN_E_DEVICE: return "no gfx950 device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
+    if (!out_plan) return MOLANN_E_NULL;
+    *out_plan = nullptr;
+    const int v = validate_desc(d);
+    if (v != MOLANN_OK) return v;
+
+    // ---- expand the feature list into items (column order = list order, ann.py:473) ------------
+    std::vector<ItemDev> items;
+    int col = 0;
+    for (int f = 0; f < d->n_features; ++f) {
+        const int* idx = d->feat_idx + d->feat_ptr[f];
+        const int cnt = d->feat_ptr[f + 1] - d->feat_ptr[f];
+        const int t = d->feat_type[f];
+        if (t == MOLANN_FEAT_POSITION) {
+            for (int i = 0; i < cnt; ++i) {
+                ItemDev it = {IT_POSITION, col, {idx[i], idx[i], idx[i], idx[i]}, {0, 0}};
+                items.push_back(it);
+                col += 3;
+            }
+        } else {
+            ItemDev it;
+            it.type = t == MOLANN_FEAT_ANGLE ? (d->use_angle_value ? IT_ANGLE_VAL : IT_ANGLE_COS)
+                      : t == MOLANN_FEAT_BOND ? IT_BOND
+                                              : (d->use_angle_value ? IT_DIHEDRAL_VAL : IT_DIHEDRAL_CS);
+            it.col = col;
+            for (int i = 0; i < 4; ++i) it.idx[i] = idx[i < cnt ? i : 0];
+            it.pad[0] = it.pad[1] = 0;
+            items.push_back(it);
+            col += item_width(it.type);
+        }
+    }
+    const int d_feat = col;
+    if (d->n_layers > 0 && d->n_features > 0 && d->layer_dims[0] != d_feat) return MOLANN_E_DESC;
+
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+
+    molann_plan* p = new (std::nothrow) molann_plan();
+    if (!p) return (int)hipErrorOutOfMemory;
+    memset(p, 0, sizeof(*p));
+    p->device = dev;
+    p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p->n_inp = d->n_inp;
+    p->n_align = d->n_align;
+    p->n_features = d->n_features;
+    p->n_items = (int)items.size();
+    p->d_feat = d_feat;
+    p->use_angle_value = d->use_angle_value;
+    p->n_layers = d->n_layers;
+    p->act = d->activation;
+    p->mlp_prec = d->mlp_precision;
+    for (int i = 0; i <= d->n_layers; ++i) p->dims[i] = d->layer_dims[i];
+    p->out_dim = d->n_layers > 0 ? d->layer_dims[d->n_layers] : d_feat;
+
+    // ---- kernel family and MLP placement -------------------------------------------------------
+    int max_w = 0;
+    for (int i = 1; i <= d->n_layers; ++i) max_w = std::max(max_w, d->layer_dims[i]);
+    const bool cheap_act = d->activation != MOLANN_ACT_ELU && d->activation != MOLANN_ACT_SOFTPLUS &&
+                           d->activation != MOLANN_ACT_GELU;
+    const bool small_mlp = d->n_layers > 0 && max_w <= LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
+    p->mlpw = max_w <= 8 ? 8 : (max_w <= 16 ? 16 : 32);
+    const int cols_needed = std::max(1, std::max(d_feat, small_mlp ? p->out_dim : 0));
+    p->family = 1;
+    if (cols_needed <= LANE_MAX_COLS && lane_geometry(p, cols_needed) == 0) p->family = 0;
+    p->fused_mlp = (p->family == 0) && small_mlp && d->n_features > 0;
+
+    // ---- device blob ----------------------------------------------------------------------------
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_align = carve(sizeof(int) * std::max(1, d->n_align));
+    const size_t o_ref = carve(sizeof(float) * (3 * (size_t)d->n_align + 8));
+    const size_t o_ref64 = carve(sizeof(double) * (3 * (size_t)d->n_align + 8));
+    const size_t o_items = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
+    size_t lane_floats = 0;
+    if (p->fused_mlp)
+        for (int l = 0; l < d->n_layers; ++l) {
+            p->woff[l] = (int)lane_floats;
+            lane_floats += (size_t)p->mlpw + (size_t)p->dims[l] * p->mlpw;
+        }
+    const size_t o_wlane = carve(sizeof(float) * std::max<size_t>(1, lane_floats));
+    size_t mfma_bytes = 0;
+    const bool bf16 = d->mlp_precision == MOLANN_MLP_BF16;
+    const int kgran = bf16 ? 32 : 16;
+    int max_kp = 16;
+    if (d->n_layers > 0) {
+        const size_t es = bf16 ? 2 : 4;
+        for (int l = 0; l < d->n_layers; ++l) {
+            p->kp[l] = ceil_to(p->dims[l], kgran);
+            p->jp[l] = ceil_to(p->dims[l + 1], 16);
+            max_kp = std::max(max_kp, std::max(p->kp[l], p->jp[l]));
+        }
+        // the activations written by layer l (Jp columns) are read as layer l+1's Kp columns
+        for (int l = 0; l + 1 < d->n_layers; ++l) max_kp = std::max(max_kp, p->kp[l + 1]);
+        for (int l = 0; l < d->n_layers; ++l) {
+            p->moff[l] = (long)(mfma_bytes / es);
+            mfma_bytes += ((size_t)p->jp[l] * p->kp[l]) * es + (size_t)p->jp[l] * 4;
+            mfma_bytes = (mfma_bytes + 15) & ~(size_t)15;
+        }
+        p->mlp_ld = max_kp + (bf16 ? 8 : 4); // row stride: 16-byte multiple, off the power of two
+        p->mlp_lds_per_wave = 2 * 16 * p->mlp_ld * (int)es;
+        if (p->mlp_lds_per_wave > 163840) { delete p; return MOLANN_E_UNSUPPORTED; }
+        if (p->mlp_lds_per_wave > 65536) { // a single wave's two activation buffers exceed the default 64 KiB cap
+            hipError_t ea = bf16 ? hipFuncSetAttribute((const void*)mlp_mfma_kernel<true>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
+                                 : hipFuncSetAttribute((const void*)mlp_mfma_kernel<false>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            if (ea != hipSuccess) { delete p; return (int)ea; }
+        }
+    }
+    const size_t o_wmfma = carve(std::max<size_t>(16, mfma_bytes));
+    p->work_frames = 0;
+    size_t work_bytes = 0;
+    if (d->n_layers > 0 && d->n_features > 0 && !p->fused_mlp) {
+        // feature chunk handed from the preprocessing kernel to the MLP kernel: sized to stay
+        // resident in the 256 MiB Infinity Cache
+        long wf = (64l << 20) / ((long)d_feat * 4);
+        wf = std::max<long>(1024, std::min<long>(wf, 1l << 18));
+        wf &= ~63l;
+        p->work_frames = wf;
+        work_bytes = (size_t)wf * d_feat * 4;
+    }
+    const size_t o_work = carve(std::max<size_t>(16, work_bytes));
+
+    hipError_t e = hipMalloc((void**)&p->blob, off);
+    if (e != hipSuccess) { delete p; return (int)e; }
+    p->d_align_idx = (int*)(p->blob + o_align);
+    p->d_ref = (float*)(p->blob + o_ref);
+    p->d_ref64 = (double*)(p->blob + o_ref64);
+    p->d_items = (ItemDev*)(p->blob + o_items);
+    p->d_wlane = (float*)(p->blob + o_wlane);
+    p->d_wmfma = (void*)(p->blob + o_wmfma);
+    p->d_work = (float*)(p->blob + o_work);
+
+    // ---- upload (synchronous: plan creation is setup time) --------------------------------------
+    if (d->n_align > 0) {
+        std::vector<float> refc(3 * (size_t)d->n_align + 8, 0.f);
+        std::vector<double> refd(3 * (size_t)d->n_align + 8, 0.);
+        double s[4] = {0, 0, 0, 0};
+        for (int i = 0; i < d->n_align; ++i) {
+            for (int c = 0; c < 3; ++c) {
+                const float r = d->ref_x[3 * i + c];
+                refc[3 * i + c] = r;
+                refd[3 * i + c] = r;
+                s[c] += r;
+                s[3] += (double)r * r;
+            }
+        }
+        float* c = refc.data() + 3 * (size_t)d->n_align;
+        double* c64 = refd.data() + 3 * (size_t)d->n_align;
+        for (int k = 0; k < 4; ++k) { c[k] = (float)s[k]; c64[k] = s[k]; }
+        c[4] = 1.0f / (float)d->n_align;
+        c[5] = (float)d->n_align;
+        c64[4] = 1.0 / (double)d->n_align;
+        c64[5] = (double)d->n_align;
+        e = hipMemcpy(p->d_align_idx, d->align_idx, sizeof(int) * d->n_align, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_ref, refc.data(), sizeof(float) * refc.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_ref64, refd.data(), sizeof(double) * refd.size(), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !items.empty())
+        e = hipMemcpy(p->d_items, items.data(), sizeof(ItemDev) * items.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
+    snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
+    *out_plan = p;
+    return MOLANN_OK;
+}
+
+int molann_plan_destroy(molann_plan* p) {
+    if (!p) return MOLANN_OK;
+    hipError_t e = hipFree(p->blob);
+    delete p;
+    return (int)e;
+}
+
+int molann_plan_feature_dim(const molann_plan* p) { return p ? p->d_feat : MOLANN_E_NULL; }
+int molann_plan_out_dim(const molann_plan* p) { return p ? p->out_dim : MOLANN_E_NULL; }
+int molann_plan_kernel_family(const molann_plan* p) { return p ? p->family : MOLANN_E_NULL; }
+
+int molann_plan_last_launch_info(const molann_plan* p, char* buf, int cap) {
+    if (!p || !buf || cap <= 0) return MOLANN_E_NULL;
+    snprintf(buf, (size_t)cap, "%s", p->last_info);
+    return (int)strlen(buf);
+}
+
+int molann_plan_update_ref(molann_plan* p, const float* ref_x, molann_stream_t stream) {
+    if (!p || !ref_x) return MOLANN_E_NULL;
+    if (p->n_align <= 0) return MOLANN_E_STAGE;
+    hipLaunchKernelGGL(pack_ref_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p->d_ref, p->d_ref64, ref_x, p->n_align);
+    return (int)hipGetLastError();
+}
+
+int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* const* b, molann_stream_t stream) {
+    if (!p || !W || !b) return MOLANN_E_NULL;
+    if (p->n_layers <= 0) return MOLANN_E_STAGE;
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_layers = p->n_layers;
+    for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
+    for (int l = 0; l < p->n_layers; ++l) {
+        if (!W[l] || !b[l]) return MOLANN_E_NULL;
+        a.W[l] = W[l]; a.b[l] = b[l];
+        a.woff[l] = p->woff[l];
+        a.kp[l] = p->kp[l]; a.jp[l] = p->jp[l]; a.moff[l] = p->moff[l];
+    }
+    a.mlpw = p->mlpw;
+    a.bf16 = p->mlp_prec == MOLANN_MLP_BF16;
+    if (p->fused_mlp)
+        hipLaunchKernelGGL(pack_lane_kernel, dim3(4, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
+    // the MFMA copy serves molann_mlp_packed_f32 and the unfused forward
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(64, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wmfma, a);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) p->mlp_packed = true;
+    return (int)e;
+}
+
+static int check_io(const void* x, const void* out, int64_t n) {
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !out) return MOLANN_E_NULL;
+    if ((((uintptr_t)x) & 3) || (((uintptr_t)out) & 3)) return MOLANN_E_ALIGNMENT;
+    return MOLANN_OK;
+}
+
+int molann_align_f32(const molann_plan* cp, const float* x, int64_t n, float* out_xyz, molann_stream_t stream) {
+    if (!cp) return MOLANN_E_NULL;
+    molann_plan* p = const_cast<molann_plan*>(cp);
+    if (p->n_align <= 0) return MOLANN_E_STAGE;
+    const int c = check_io(x, out_xyz, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    return launch_pre(p, x, n, out_xyz, 1, false, (hipStream_t)stream);
+}
+
+int molann_features_f32(const molann_plan* cp, const float* x, int64_t n, float* out, molann_stream_t stream) {
+    if (!cp) return MOLANN_E_NULL;
+    molann_plan* p = const_cast<molann_plan*>(cp);
+    if (p->n_items <= 0) return MOLANN_E_STAGE;
+    const int c = check_io(x, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    return launch_pre(p, x, n, out, 0, false, (hipStream_t)stream);
+}
+
+int molann_mlp_packed_f32(const molann_plan* cp, const float* f, int64_t n, float* out, molann_stream_t stream) {
+    if (!cp) return MOLANN_E_NULL;
+    molann_plan* p = const_cast<molann_plan*>(cp);
+    if (p->n_layers <= 0) return MOLANN_E_STAGE;
+    if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    const int c = check_io(f, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    return launch_mlp(p, f, n, p->dims[0], out, (hipStream_t)stream);
+}
+
+int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, float* out, molann_stream_t stream) {
+    if (!cp) return MOLANN_E_NULL;
+    molann_plan* p = const_cast<molann_plan*>(cp);
+    if (p->n_layers <= 0 || p->n_items <= 0) return MOLANN_E_STAGE;
+    if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    const int c = check_io(x, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    if (p->fused_mlp) return launch_pre(p, x, n, out, 0, true, (hipStream_t)stream);
+    // unfused: features of a chunk -> plan workspace (cache resident) -> MFMA MLP
+    char info[256];
+    info[0] = 0;
+    for (int64_t s = 0; s < n; s += p->work_frames) {
+        const long m = (long)std::min<int64_t>(p->work_frames, n - s);
+        int e = launch_pre(p, x + s * (long)p->n_inp * 3, m, p->d_work, 0, false, (hipStream_t)stream);
+        if (e != 0) return e;
+        if (s == 0) snprintf(info, sizeof(info), "%s", p->last_info);
+        e = launch_mlp(p, p->d_work, m, p->d_feat, out + s * (long)p->out_dim, (hipStream_t)stream);
+        if (e != 0) return e;
+    }
+    snprintf(p->last_info, sizeof(p->last_info), "%.180s + mlp_mfma_kernel<%s> chunk=%ld", info,
+             p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->work_frames);
+    return MOLANN_OK;
+}
+
+int molann_forward_f32(molann_plan* p, const float* x, int64_t n, const float* const* W, const float* const* b,
+                       float* out, molann_stream_t stream) {
+    const int e = molann_plan_update_mlp(p, W, b, stream);
+    if (e != MOLANN_OK) return e;
+    return molann_forward_packed_f32(p, x, n, out, stream);
+}
+
+// ---- self-test hooks: the same __host__ __device__ source, compiled for the host -------------
+int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9) {
+    if (!H9 || !R9) return MOLANN_E_NULL;
+    double h[9];
+    float r[9];
+    for (int i = 0; i < 9; ++i) h[i] = H9[i];
+    kabsch_rotation(h, e0, r);
+    for (int i = 0; i < 9; ++i) R9[i] = r[i];
+    return MOLANN_OK;
+}
+
+int molann_selftest_feature(int type, int use_angle_value, const float* a, float* out3) {
+    if (!a || !out3) return MOLANN_E_NULL;
+    int it;
+    if (type == MOLANN_FEAT_ANGLE) it = use_angle_value ? IT_ANGLE_VAL : IT_ANGLE_COS;
+    else if (type == MOLANN_FEAT_BOND) it = IT_BOND;
+    else if (type == MOLANN_FEAT_DIHEDRAL) it = use_angle_value ? IT_DIHEDRAL_VAL : IT_DIHEDRAL_CS;
+    else if (type == MOLANN_FEAT_POSITION) it = IT_POSITION;
+    else return MOLANN_E_FEATURE;
+    float v[3] = {0.f, 0.f, 0.f};
+    const int w = eval_item(it, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), v);
+    for (int i = 0; i < w; ++i) out3[i] = v[i];
+    return w;
+}
+
+float molann_selftest_activation(int act, float v) { return apply_activation(act, v); }
+
+} // extern "C"

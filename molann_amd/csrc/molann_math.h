@@ -1,0 +1,271 @@
+// molann_math.h - per-frame arithmetic of the molann forward path, written once as
+// __host__ __device__ code: the gfx950 kernels inline it, and the molann_selftest_* hooks compile the
+// same source for the host so the CPU test-suite can check it against the oracle.
+//
+//   features      molann/ann.py:323-354   (angle / bond / dihedral / position)
+//   kabsch        molann/ann.py:187-195   (rotation from the 3x3 covariance)
+//   activations   molann/ann.py:37,64     (the module placed between the Linear layers)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define MOLANN_HD __host__ __device__ __forceinline__
+
+namespace molann {
+
+// item types of the expanded feature table (one output column group each)
+enum ItemType : int {
+    IT_ANGLE_COS = 0,   // ann.py:328-332, use_angle_value = False
+    IT_BOND = 1,        // ann.py:334-336
+    IT_DIHEDRAL_CS = 2, // ann.py:344-351, [cos, sin]
+    IT_POSITION = 3,    // ann.py:353-354, one atom (3 columns); a k-atom feature is k items
+    IT_ANGLE_VAL = 4,   // ann.py:330 acos
+    IT_DIHEDRAL_VAL = 5 // ann.py:349 atan2
+};
+
+struct V3 {
+    float x, y, z;
+};
+
+MOLANN_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+MOLANN_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MOLANN_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MOLANN_HD float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+MOLANN_HD V3 cross(V3 a, V3 b) {
+    return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+// ---- fast scalar helpers (device: one hardware instruction; host: libm) -----------------------
+MOLANN_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+MOLANN_HD float fast_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+
+// ---- features ---------------------------------------------------------------------------------
+// bond length |x2 - x1| (ann.py:335-336)
+MOLANN_HD float feat_bond(V3 a0, V3 a1) {
+    V3 r = a1 - a0;
+    return sqrtf(dot(r, r));
+}
+
+// cosine of the angle at the SECOND atom (ann.py:324-328); no clamp, as in the reference
+MOLANN_HD float feat_angle_cos(V3 a0, V3 a1, V3 a2) {
+    V3 r21 = a0 - a1;
+    V3 r23 = a2 - a1;
+    float l21 = sqrtf(dot(r21, r21));
+    float l23 = sqrtf(dot(r23, r23));
+    return dot(r21, r23) / (l21 * l23);
+}
+
+// unnormalised (cos, sin) of the dihedral 1-2-3-4 (ann.py:339-345)
+MOLANN_HD void feat_dihedral_raw(V3 a0, V3 a1, V3 a2, V3 a3, float& c, float& s) {
+    V3 r12 = a1 - a0;
+    V3 r23 = a2 - a1;
+    V3 r34 = a3 - a2;
+    V3 n1 = cross(r12, r23);
+    V3 n2 = cross(r23, r34);
+    c = dot(n1, n2);
+    s = dot(n1, r34) * sqrtf(dot(r23, r23));
+}
+
+// One item of the feature table on up to four atoms; writes 1..3 values, returns how many.
+MOLANN_HD int eval_item(int type, V3 a0, V3 a1, V3 a2, V3 a3, float (&out)[3]) {
+    switch (type) {
+    case IT_ANGLE_COS:
+        out[0] = feat_angle_cos(a0, a1, a2);
+        return 1;
+    case IT_ANGLE_VAL:
+        out[0] = acosf(feat_angle_cos(a0, a1, a2)); // ann.py:330
+        return 1;
+    case IT_BOND:
+        out[0] = feat_bond(a0, a1);
+        return 1;
+    case IT_DIHEDRAL_CS: {
+        float c, s;
+        feat_dihedral_raw(a0, a1, a2, a3, c, s);
+        float radius = sqrtf(fmaf(c, c, s * s)); // ann.py:346
+        out[0] = c / radius;                     // ann.py:351 cos first, then sin
+        out[1] = s / radius;
+        return 2;
+    }
+    case IT_DIHEDRAL_VAL: {
+        float c, s;
+        feat_dihedral_raw(a0, a1, a2, a3, c, s);
+        out[0] = atan2f(s, c); // ann.py:349
+        return 1;
+    }
+    default: // IT_POSITION
+        out[0] = a0.x;
+        out[1] = a0.y;
+        out[2] = a0.z;
+        return 3;
+    }
+}
+
+MOLANN_HD int item_width(int type) { return type == IT_POSITION ? 3 : (type == IT_DIHEDRAL_CS ? 2 : 1); }
+MOLANN_HD int item_atoms(int type) {
+    return (type == IT_BOND) ? 2 : (type == IT_POSITION) ? 1 : (type == IT_ANGLE_COS || type == IT_ANGLE_VAL) ? 3 : 4;
+}
+
+// ---- activations ------------------------------------------------------------------------------
+// tanh to a few ulp: odd polynomial below 1/8 (no cancellation), (1-t)/(1+t), t = e^{-2|x|} above.
+MOLANN_HD float act_tanh(float x) {
+    float ax = fabsf(x);
+    float t = fast_exp(-2.0f * ax);
+    float big = (1.0f - t) * fast_rcp(1.0f + t);
+    float x2 = x * x;
+    float poly = fmaf(x2, fmaf(x2, fmaf(x2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    float r = (ax < 0.125f) ? ax * poly : big;
+    return copysignf(r, x);
+}
+
+MOLANN_HD float act_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+MOLANN_HD float apply_activation(int act, float v) {
+    switch (act) {
+    case 0: return act_tanh(v);                       // torch.nn.Tanh (the default, ann.py:37)
+    case 1: return fmaxf(v, 0.0f) + (v != v ? v : 0.0f); // ReLU, NaN-propagating like torch
+    case 2: return act_sigmoid(v);                    // Sigmoid
+    case 3: return v;                                 // Identity
+    case 4: return v > 0.0f ? v : expm1f(v);          // ELU(alpha=1)
+    case 5: return v * act_sigmoid(v);                // SiLU
+    case 6: return v > 20.0f ? v : log1pf(expf(v));   // Softplus(beta=1, threshold=20)
+    case 7: return v > 0.0f ? v : 0.01f * v;          // LeakyReLU(0.01)
+    case 8: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); // GELU (erf)
+    default: return v;
+    }
+}
+
+// ---- Kabsch rotation --------------------------------------------------------------------------
+// Input: H[a][b] = sum_i p_i[a] * ref_i[b] over the align atoms (p centred frame coordinates, ref the
+// centred reference) = `prod` of ann.py:187, accumulated in fp64 by the callers (the products of fp32
+// coordinates are exact in fp64, so H carries no rounding of its own), and
+// e0 >= (sum|p|^2 + sum|ref|^2)/2, an upper bound on the largest eigenvalue used as the Newton start.
+// Output: R (row-major) with aligned_row = p_row . R, equal to U diag(1,1,sign det(U Vh)) Vh of
+// ann.py:188-195.
+//
+// Method (not the reference's LAPACK SVD): the optimal proper rotation is the top eigenvector of
+// Horn's symmetric 4x4 matrix K(H) read as a unit quaternion.  Its eigenvalues are
+// {s1+s2+d*s3, s1-s2-d*s3, -s1+s2-d*s3, -s1-s2+d*s3} (s = singular values, d = sign det H), so the top
+// one is simple exactly when the rotation is well defined (s2 + d*s3 > 0): rank-2 covariances (planar
+// reference, three align atoms) and reflections need no special case.  lambda_max by Newton on the
+// characteristic quartic from above (monotone), eigenvector = the column of adj(K - lambda I) with the
+// largest diagonal entry.  fp64 throughout: ~250 flops per frame, against ~60 flops to form H.
+MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) {
+    double fro2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fro2 = fma(H[i], H[i], fro2);
+    if (!(fro2 > 1e-60) || !(fro2 < 1e60)) { // zero / non-finite covariance: no rotation
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        return;
+    }
+    const double s = 1.0 / sqrt(fro2); // scale so that |h|_F = 1: the rotation does not depend on it
+    const double hxx = H[0] * s, hxy = H[1] * s, hxz = H[2] * s;
+    const double hyx = H[3] * s, hyy = H[4] * s, hyz = H[5] * s;
+    const double hzx = H[6] * s, hzy = H[7] * s, hzz = H[8] * s;
+
+    const double k00 = hxx + hyy + hzz, k01 = hyz - hzy, k02 = hzx - hxz, k03 = hxy - hyx;
+    const double k11 = hxx - hyy - hzz, k12 = hxy + hyx, k13 = hzx + hxz;
+    const double k22 = -hxx + hyy - hzz, k23 = hyz + hzy;
+    const double k33 = -hxx - hyy + hzz;
+
+    // characteristic polynomial l^4 + c2 l^2 + c1 l + c0 (trace K = 0)
+    const double c2 = -2.0 * (hxx * hxx + hxy * hxy + hxz * hxz + hyx * hyx + hyy * hyy + hyz * hyz + hzx * hzx +
+                              hzy * hzy + hzz * hzz);
+    const double det_h = hxx * (hyy * hzz - hyz * hzy) - hxy * (hyx * hzz - hyz * hzx) + hxz * (hyx * hzy - hyy * hzx);
+    const double c1 = -8.0 * det_h;
+    double c0;
+    {
+        const double s0 = k00 * k11 - k01 * k01, s1 = k00 * k12 - k01 * k02, s2 = k00 * k13 - k01 * k03;
+        const double s3 = k01 * k12 - k11 * k02, s4 = k01 * k13 - k11 * k03, s5 = k02 * k13 - k12 * k03;
+        const double d5 = k22 * k33 - k23 * k23, d4 = k12 * k33 - k13 * k23, d3 = k12 * k23 - k13 * k22;
+        const double d2 = k02 * k33 - k03 * k23, d1 = k02 * k23 - k03 * k22, d0 = k02 * k13 - k03 * k12;
+        c0 = s0 * d5 - s1 * d4 + s2 * d3 + s3 * d2 - s4 * d1 + s5 * d0;
+    }
+
+    // Newton from above; lambda_max <= s1+s2+s3 <= sqrt(3) |h|_F and <= e0 * s
+    double lam = fmin(e0 * s, 1.7320508075688772);
+    if (!(lam > 0.0)) lam = 1.7320508075688772;
+    bool done = false;
+    for (int it = 0; it < 48; ++it) { // bounded: every lane reaches the exit
+        if (!done) {
+            const double l2 = lam * lam;
+            const double p = (l2 + c2) * l2 + c1 * lam + c0;
+            const double dp = (4.0 * l2 + 2.0 * c2) * lam + c1;
+            // Newton corrects itself: an fp32-accurate reciprocal is enough
+            const double step = p * (double)fast_rcp((float)dp);
+            const double nl = lam - step;
+            const bool finite = (step == step) && (fabs(nl) < 4.0);
+            if (finite) lam = nl;
+            if (!finite || !(fabs(step) > 1e-14 * fabs(nl))) done = true;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__all(done)) break; // wave-uniform exit
+#else
+        if (done) break;
+#endif
+    }
+
+    // adj(K - lam I) = const * q q^T
+    const double m00 = k00 - lam, m11 = k11 - lam, m22 = k22 - lam, m33 = k33 - lam;
+    const double s0 = m00 * m11 - k01 * k01, s1 = m00 * k12 - k01 * k02, s2 = m00 * k13 - k01 * k03;
+    const double s3 = k01 * k12 - m11 * k02, s4 = k01 * k13 - m11 * k03, s5 = k02 * k13 - k12 * k03;
+    const double d5 = m22 * m33 - k23 * k23, d4 = k12 * m33 - k13 * k23, d3 = k12 * k23 - k13 * m22;
+    const double d2 = k02 * m33 - k03 * k23, d1 = k02 * k23 - k03 * m22;
+    const double a00 = m11 * d5 - k12 * d4 + k13 * d3;
+    const double a01 = -k01 * d5 + k02 * d4 - k03 * d3;
+    const double a02 = k13 * s5 - k23 * s4 + m33 * s3;
+    const double a03 = -k12 * s5 + m22 * s4 - k23 * s3;
+    const double a11 = m00 * d5 - k02 * d2 + k03 * d1;
+    const double a12 = -k03 * s5 + k23 * s2 - m33 * s1;
+    const double a13 = k02 * s5 - m22 * s2 + k23 * s1;
+    const double a22 = k03 * s4 - k13 * s2 + m33 * s0;
+    const double a23 = -k02 * s4 + k12 * s2 - k23 * s0;
+    const double a33 = k02 * s3 - k12 * s1 + m22 * s0;
+
+    // column with the largest |diagonal| (q_j^2 >= 1/4 there)
+    double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
+    if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+    if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+    if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+    const double n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    if (!(n2 > 0.0) || !(n2 < 1e300)) { // K - lam I numerically zero: degenerate input
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        return;
+    }
+    const double inv = 1.0 / n2;
+    const double ww = q0 * q0 * inv, xx = q1 * q1 * inv, yy = q2 * q2 * inv, zz = q3 * q3 * inv;
+    const double wx = q0 * q1 * inv, wy = q0 * q2 * inv, wz = q0 * q3 * inv;
+    const double xy = q1 * q2 * inv, xz = q1 * q3 * inv, yz = q2 * q3 * inv;
+    // Q (column convention, maps frame -> reference); R = Q^T for row vectors
+    R[0] = (float)(ww + xx - yy - zz);
+    R[1] = (float)(2.0 * (xy + wz));
+    R[2] = (float)(2.0 * (xz - wy));
+    R[3] = (float)(2.0 * (xy - wz));
+    R[4] = (float)(ww - xx + yy - zz);
+    R[5] = (float)(2.0 * (yz + wx));
+    R[6] = (float)(2.0 * (xz + wy));
+    R[7] = (float)(2.0 * (yz - wx));
+    R[8] = (float)(ww - xx - yy + zz);
+}
+
+// y = p . R  (row vector times row-major R)
+MOLANN_HD V3 rotate(V3 p, const float (&R)[9]) {
+    return v3(fmaf(p.z, R[6], fmaf(p.y, R[3], p.x * R[0])), fmaf(p.z, R[7], fmaf(p.y, R[4], p.x * R[1])),
+              fmaf(p.z, R[8], fmaf(p.y, R[5], p.x * R[2])));
+}
+
+} // namespace molann

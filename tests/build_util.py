@@ -1,0 +1,78 @@
+"""Build the PRODUCT modules (molann_amd.ann) for a golden case, from its 1-based atom numbers."""
+
+import numpy as np
+import torch
+
+from molann_amd import workloads as wl
+from molann_amd.ann import (AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn)
+from molann_amd.atomgroup import Universe
+from molann_amd.feature import Feature
+
+_ACTS = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU, "sigmoid": torch.nn.Sigmoid}
+_chain = {}
+
+
+def universe_for(case):
+    top = max(case.input_ix) + 1
+    if top <= 22:
+        return Universe(wl.ALA_DIPEPTIDE_XYZ)
+    if "chain" not in _chain:
+        _chain["chain"] = Universe(wl.synthetic_chain())
+    return _chain["chain"]
+
+
+def build_modules(case, device=None, mlp_precision="f32"):
+    """(model, kind): AlignmentLayer / PreprocessingANN / MolANN exactly as the case describes."""
+    u = universe_for(case)
+    input_ag = u.atoms_by_number([i + 1 for i in case.input_ix])
+    alayer = AlignmentLayer(u.atoms_by_number(case.align_numbers), input_ag) if case.has_align else None
+    flayer = None
+    if case.features_numbers:
+        feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number(nums))
+                 for i, (t, nums) in enumerate(case.features_numbers)]
+        flayer = FeatureLayer(feats, input_ag, case.use_angle_value)
+    if case.kind == "align":
+        model = alayer
+    elif case.kind == "features":
+        model = PreprocessingANN(alayer, flayer)
+    else:
+        nn = create_sequential_nn(case.mlp_dims, activation=_ACTS[case.activation]())
+        lins = [m for m in nn if isinstance(m, torch.nn.Linear)]
+        with torch.no_grad():
+            for lin, w, b in zip(lins, case.weights, case.biases):
+                lin.weight.copy_(w)
+                lin.bias.copy_(b)
+        model = MolANN(PreprocessingANN(alayer, flayer), nn, mlp_precision=mlp_precision)
+    if device is not None:
+        model = model.to(device)
+    return model
+
+
+def workload_model(w, device=None, seed=0):
+    """The product model of a BASELINE workload (input group = all atoms)."""
+    u = Universe(w.ref_xyz)
+    input_ag = u.atoms
+    alayer = AlignmentLayer(u.atoms_by_number(w.align), input_ag) if w.align is not None else None
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number(atoms)) for i, (t, atoms) in enumerate(w.features)]
+    pp = PreprocessingANN(alayer, FeatureLayer(feats, input_ag, w.use_angle_value))
+    if not w.mlp_dims:
+        model = pp
+    else:
+        torch.manual_seed(seed)
+        model = MolANN(pp, create_sequential_nn(w.mlp_dims), mlp_precision=("bf16" if w.mlp_dtype == "bf16" else "f32"))
+    return model.to(device) if device is not None else model
+
+
+def oracle_for_workload(w, model, x, dtype=torch.float32):
+    """Oracle output for a product model built by workload_model (weights read from the model)."""
+    from oracle import molann_oracle as mo
+    feats = [(t, [a - 1 for a in atoms]) for t, atoms in w.features]
+    al = [a - 1 for a in w.align] if w.align is not None else None
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[[a - 1 for a in w.align]])).to(dtype) if al else None
+    x = x.detach().cpu().to(dtype)
+    if not w.mlp_dims:
+        return mo.preprocessing_forward(x, feats, w.use_angle_value, al, ref_x)
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    ws = [l.weight.detach().cpu().to(dtype) for l in lins]
+    bs = [l.bias.detach().cpu().to(dtype) for l in lins]
+    return mo.molann_forward(x, feats, ws, bs, w.use_angle_value, al, ref_x)
