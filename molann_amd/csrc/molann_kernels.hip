@@ -929,7 +929,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->n_layers = d->n_layers;
     p->act = d->activation;
     p->mlp_prec = d->mlp_precision;
-    for (int i = 0; i <= d->n_layers; ++i) p->dims[i] = d->layer_dims[i];
+    if (d->n_layers > 0)
+        for (int i = 0; i <= d->n_layers; ++i) p->dims[i] = d->layer_dims[i];
     p->out_dim = d->n_layers > 0 ? d->layer_dims[d->n_layers] : d_feat;
 
     // ---- kernel family and MLP placement -------------------------------------------------------
