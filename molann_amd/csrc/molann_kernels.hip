@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -58,6 +59,9 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
 struct ItemDev { // one expanded feature item, 32 bytes
     int type;    // ItemType
     int col;     // first output column
@@ -66,7 +70,8 @@ struct ItemDev { // one expanded feature item, 32 bytes
 };
 
 constexpr int FB_STRIDE = 65; // feature/activation staging [col][FB_STRIDE]: lane-contiguous, odd stride
-constexpr int LANE_MLP_MAX_WIDTH = 32;
+constexpr int LANE_MLP_MAX_WIDTH = 32;  // widths (and the feature dim) the fused MFMA MLP covers
+constexpr int LANE_MLP_MAX_LAYERS = 4;
 constexpr int LANE_MAX_COLS = 128; // widest feature / output row the lane kernel stages in LDS
 
 // ---------------------------------------------------------------------------------------------
@@ -86,10 +91,11 @@ struct PreArgs {
     int fbuf_off;     // byte offset of the staging buffer inside the wave's region
     int x_wide;       // x is 16-byte aligned
     int out_wide;     // out is 16-byte aligned
+    int out_vec4;     // fused MLP: out rows can be written with 16-byte stores
     int n_layers;     // fused MLP (lane kernel only); 0 = none
     int act;
     int dims[MOLANN_MAX_LAYERS + 1];
-    int woff[MOLANN_MAX_LAYERS]; // float offset of layer l inside wpack: bias[W], then W[k][W]
+    int ablate;       // diagnostic only (MOLANN_DEBUG_ABLATE): skip stages to price them; 0 in production
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -168,16 +174,84 @@ __device__ __forceinline__ void activate(int act, float (&h)[W]) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// lane-kernel helpers
+// ---------------------------------------------------------------------------------------------
+// Plan constants (align table, feature table) are held one record per LANE in VGPRs for the whole
+// kernel and broadcast with v_readlane when a loop needs record i: no memory access, no latency.
+__device__ __forceinline__ int bcast(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ double bcast(double v, int i) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), i), hi = __builtin_amdgcn_readlane((int)(b >> 32), i);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// HBM -> LDS for one tile of up to 64 WHOLE frames (contiguous in HBM): LDS-DMA, 16 B per lane when x is
+// 16-byte aligned, else 4 B per lane.  LDS image = the HBM bytes: [frame][atom][xyz].  Used when every
+// atom is needed (AlignmentLayer.forward).  Returns without waiting; the consumer waits on vmcnt.
+__device__ __forceinline__ void stage_tile_dense(const float* __restrict__ x, float* tile, long t, const PreArgs& a, int lane) {
+    // WAR: every LDS read of the tile's previous contents has returned before the DMA may overwrite it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int frame_bytes = a.frame_dw * 4;
+    const long rem = a.n_frames - t * 64;
+    const int nfr = rem < 64 ? (int)rem : 64;
+    const int valid_bytes = nfr * frame_bytes;
+    const unsigned char* gsrc = (const unsigned char*)x + t * ((long)frame_bytes * 64);
+    if (a.x_wide) {
+        const int nchunk = valid_bytes >> 4;
+        for (int c0 = 0; c0 < nchunk; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < nchunk) glds16(gsrc + (size_t)c * 16, (unsigned char*)tile + (size_t)c0 * 16);
+        }
+        const int rem_dw = (valid_bytes & 15) >> 2;
+        if (lane < rem_dw) glds4(gsrc + (size_t)nchunk * 16 + lane * 4, (unsigned char*)tile + (size_t)nchunk * 16);
+    } else {
+        const int ndw = valid_bytes >> 2;
+        for (int c0 = 0; c0 < ndw; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < ndw) glds4(gsrc + (size_t)c * 4, (unsigned char*)tile + (size_t)c0 * 4);
+        }
+    }
+}
+
+// atom k of this lane's frame row in the LDS tile
+__device__ __forceinline__ V3 lds_atom(const float* fr, int k) { return v3(fr[3 * k], fr[3 * k + 1], fr[3 * k + 2]); }
+
+template <int N>
+__device__ __forceinline__ f32x4 mfma_chain(const float (&wa)[8], int w0, const float* b, f32x4 acc) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[w0 + k], b[k], acc, 0, 0, 0);
+    return acc;
+}
+
 // =============================================================================================
 // frames_lane_kernel: one lane per frame, 64-frame tiles staged through LDS by LDS-DMA
 // =============================================================================================
-template <int MLPW>
+// ALIGN_OUT = true : AlignmentLayer.forward, aligned frames written back.
+// ALIGN_OUT = false: features (+ fused MLP when NL > 0).
+// (Staging only the touched atoms with per-lane-address 12-byte LDS-DMA was measured and rejected: it
+// halves the LDS footprint but each such instruction touches 64 different 128-B lines, ~9 us per staged
+// atom per 1M frames against 66 us for the whole dense tile.)
+//
+// Fused MLP (NL Linear layers, every width <= 32, feature dim <= 32) on the fp32-input MFMA
+// v_mfma_f32_16x16x4_f32, computed TRANSPOSED: D[unit][frame] = W[unit][k] . X[k][frame].
+//   * A operand = weights: lane (i = l&15, q = l>>4) holds W[16ub + i][k(q)] - loaded ONCE per kernel
+//     into registers (wfrag, laid out per lane by pack_lane_kernel), never re-read.
+//   * B operand = activations: lane (frame = l&15, q) holds X[k(q)][frame].  Layer 0 reads the features
+//     from the wave's staging buffer, k(q) = 4 ks + q.  For the following layers the k-steps are
+//     enumerated as (ub', r) with k(q) = 16 ub' + 4 q + r, which is exactly the (row 4q + r, col frame)
+//     element the previous layer's accumulator register r of unit block ub' holds in that same lane:
+//     the accumulator IS the next B operand, no shuffle and no LDS round trip between layers.
+//   * The last layer's accumulator holds out[frame][16ub + 4q + r], r = 0..3: one 16-byte store per
+//     lane, whole output rows per 16-lane group.
+// fp32 MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so this is fp32 math.
+template <int NL, bool ALIGN_OUT>
 __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          const int* __restrict__ align_idx_g,
+                                                          const int* __restrict__ align_tbl_g,
                                                           const float* __restrict__ ref_g,    // [a*3] + consts
                                                           const double* __restrict__ ref64_g, // same, fp64
                                                           const ItemDev* __restrict__ items_g,
-                                                          const float* __restrict__ wpack_g, PreArgs a) {
+                                                          const float* __restrict__ wfrag_g, PreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -185,46 +259,56 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
     unsigned char* wreg = smem + (size_t)wave * a.lds_per_wave;
     float* tile = (float*)wreg;
     float* fbuf = (float*)(wreg + a.fbuf_off);
-
-    const auto align_idx = as_const(align_idx_g);
     const auto ref = as_const(ref_g);
     const auto ref64 = as_const(ref64_g);
-    const auto items = as_const((const int*)items_g);
-    const auto wpack = as_const(wpack_g);
 
     const long n_tiles = (a.n_frames + 63) >> 6;
-    const int frame_bytes = a.frame_dw * 4;
-    const long tile_bytes = (long)frame_bytes * 64;
+    const long t_first = (long)blockIdx.x * wpb + wave;
+    const long t_step = (long)gridDim.x * wpb;
 
-    // read-out position of this lane: element e = it*64 + lane of the [64][out_cols] tile
+    // ---- per-kernel constants, one record per lane (broadcast later with v_readlane) -----------
+    if (t_first < n_tiles) stage_tile_dense(x, tile, t_first, a, lane); // first tile in flight while constants load
+    const bool has_align = a.n_align > 0;
+    int al_idx = 0;
+    double al_rx = 0., al_ry = 0., al_rz = 0.;
+    if (has_align && lane < a.n_align) {
+        al_idx = align_tbl_g[lane];
+        al_rx = ref64_g[3 * lane]; al_ry = ref64_g[3 * lane + 1]; al_rz = ref64_g[3 * lane + 2];
+    }
+    int it_type = 0, it_col = 0, it_i0 = 0, it_i1 = 0, it_i2 = 0, it_i3 = 0;
+    if (!ALIGN_OUT && lane < a.n_items) {
+        const int4 d0 = ((const int4*)items_g)[2 * lane];
+        const int2 d1 = ((const int2*)items_g)[4 * lane + 2];
+        it_type = d0.x; it_col = d0.y; it_i0 = d0.z; it_i1 = d0.w; it_i2 = d1.x; it_i3 = d1.y;
+    }
+    float wA[NL > 0 ? NL : 1][2][8];
+    f32x4 wB[NL > 0 ? NL : 1][2];
+    if constexpr (NL > 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) wA[l][ub][ks] = wfrag_g[((l * 2 + ub) * 8 + ks) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wB[l][ub][r] = wfrag_g[NL * 1024 + ((l * 2 + ub) * 4 + r) * 64 + lane];
+            }
+        // feature rows beyond the feature dim feed zero weights: keep them finite
+        for (int c = a.dims[0]; c < ((a.dims[0] + 3) & ~3); ++c) fbuf[c * FB_STRIDE + lane] = 0.f;
+    }
+    const int i16 = lane & 15, q4 = lane >> 4;
+
+    // read-out position of this lane (no fused MLP): element e = it*64 + lane of the [64][out_cols] tile
     int ro_f0 = 0, ro_c0 = 0;
-    if (a.mode == 0) {
+    if (!ALIGN_OUT && NL == 0) {
         ro_f0 = lane / a.out_cols;
         ro_c0 = lane - ro_f0 * a.out_cols;
     }
 
-    for (long t = (long)blockIdx.x * wpb + wave; t < n_tiles; t += (long)gridDim.x * wpb) {
+    for (long t = t_first; t < n_tiles; t += t_step) {
         const long rem = a.n_frames - t * 64;
         const int nfr = rem < 64 ? (int)rem : 64;
-        const int valid_bytes = nfr * frame_bytes;
-        const unsigned char* gsrc = (const unsigned char*)x + t * tile_bytes;
-
-        // ---- 1. HBM -> LDS, whole frames, contiguous ------------------------------------------
-        if (a.x_wide) {
-            const int nchunk = valid_bytes >> 4;
-            for (int c0 = 0; c0 < nchunk; c0 += 64) {
-                const int c = c0 + lane;
-                if (c < nchunk) glds16(gsrc + (size_t)c * 16, (unsigned char*)tile + (size_t)c0 * 16);
-            }
-            const int rem_dw = (valid_bytes & 15) >> 2;
-            if (lane < rem_dw) glds4(gsrc + (size_t)nchunk * 16 + lane * 4, (unsigned char*)tile + (size_t)nchunk * 16);
-        } else {
-            const int ndw = valid_bytes >> 2;
-            for (int c0 = 0; c0 < ndw; c0 += 64) {
-                const int c = c0 + lane;
-                if (c < ndw) glds4(gsrc + (size_t)c * 4, (unsigned char*)tile + (size_t)c0 * 4);
-            }
-        }
+        // ---- 1. the tile was requested one iteration ago (or above): wait for the LDS-DMA -------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // lanes past the end of the batch recompute the last valid frame (their stores are masked)
@@ -234,16 +318,16 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
         // ---- 2. Kabsch (ann.py:179-195) --------------------------------------------------------
         float R[9];
         V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
-        const bool has_align = a.n_align > 0;
         if (has_align) {
-            const int k0 = align_idx[0];
-            c0 = v3(fr[3 * k0], fr[3 * k0 + 1], fr[3 * k0 + 2]); // provisional centre: first align atom
+            c0 = lds_atom(fr, bcast(al_idx, 0)); // provisional centre: first align atom
             float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
             double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
-            for (int i = 0; i < a.n_align; ++i) {
-                const int k = align_idx[i];
-                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
-                const V3 p = v3(fr[3 * k], fr[3 * k + 1], fr[3 * k + 2]) - c0;
+            const int na = (a.ablate & 8) ? 1 : a.n_align;
+#pragma unroll 4
+            for (int i = 0; i < na; ++i) {
+                const int k = bcast(al_idx, i);
+                const double rx = bcast(al_rx, i), ry = bcast(al_ry, i), rz = bcast(al_rz, i);
+                const V3 p = lds_atom(fr, k) - c0;
                 sx += p.x; sy += p.y; sz += p.z;
                 g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
                 const double px = p.x, py = p.y, pz = p.z;
@@ -262,12 +346,20 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
             h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
             h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
             const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
-            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+            if (a.ablate & 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) R[i] = (float)h[i];
+            } else {
+                kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+            }
         }
 
-        if (a.mode == 1) {
+        if constexpr (ALIGN_OUT) {
             // ---- 3a. AlignmentLayer.forward: every atom, in place, then LDS -> HBM ------------
+            const int frame_bytes = a.frame_dw * 4;
+            const int valid_bytes = nfr * frame_bytes;
             float* frw = tile + fl * a.frame_dw;
+#pragma unroll 2
             for (int k = 0; k < a.n_inp; ++k) {
                 const V3 p = (v3(frw[3 * k], frw[3 * k + 1], frw[3 * k + 2]) - c0) - dl;
                 const V3 y = rotate(p, R); // ann.py:197
@@ -275,7 +367,7 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                     frw[3 * k] = y.x; frw[3 * k + 1] = y.y; frw[3 * k + 2] = y.z;
                 }
             }
-            unsigned char* gdst = (unsigned char*)out + t * tile_bytes;
+            unsigned char* gdst = (unsigned char*)out + t * ((long)frame_bytes * 64);
             if (a.out_wide) {
                 const int nchunk = valid_bytes >> 4;
                 for (int c = lane; c < nchunk; c += 64) ((float4*)gdst)[c] = ((const float4*)tile)[c];
@@ -285,85 +377,119 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                 const int ndw = valid_bytes >> 2;
                 for (int c = lane; c < ndw; c += 64) ((float*)gdst)[c] = tile[c];
             }
-            continue;
-        }
-
-        // ---- 3b. feature table (ann.py:323-354, 473) -> fbuf[col][lane] -----------------------
-        for (int it = 0; it < a.n_items; ++it) {
-            const int type = items[8 * it], col = items[8 * it + 1];
-            const int i0 = items[8 * it + 2], i1 = items[8 * it + 3], i2 = items[8 * it + 4], i3 = items[8 * it + 5];
-            V3 p0 = v3(fr[3 * i0], fr[3 * i0 + 1], fr[3 * i0 + 2]);
-            V3 p1 = p0, p2 = p0, p3 = p0;
-            if (type != IT_POSITION) {
-                p1 = v3(fr[3 * i1], fr[3 * i1 + 1], fr[3 * i1 + 2]);
-                if (type != IT_BOND) {
-                    p2 = v3(fr[3 * i2], fr[3 * i2 + 1], fr[3 * i2 + 2]);
-                    if (type == IT_DIHEDRAL_CS || type == IT_DIHEDRAL_VAL) p3 = v3(fr[3 * i3], fr[3 * i3 + 1], fr[3 * i3 + 2]);
+            if (t + t_step < n_tiles) stage_tile_dense(x, tile, t + t_step, a, lane);
+        } else {
+            // ---- 3b. feature table (ann.py:323-354, 473) -> fbuf[col][lane] -------------------
+            const int n_items = (a.ablate & 2) ? 0 : a.n_items;
+            for (int it = 0; it < n_items; ++it) {
+                int type, col, i0, i1, i2, i3;
+                if (it < 64) {
+                    type = bcast(it_type, it); col = bcast(it_col, it);
+                    i0 = bcast(it_i0, it); i1 = bcast(it_i1, it); i2 = bcast(it_i2, it); i3 = bcast(it_i3, it);
+                } else { // long tables (identity features over many atoms): the rest comes from memory
+                    const auto items = as_const((const int*)items_g);
+                    type = items[8 * it]; col = items[8 * it + 1];
+                    i0 = items[8 * it + 2]; i1 = items[8 * it + 3]; i2 = items[8 * it + 4]; i3 = items[8 * it + 5];
                 }
-            }
-            if (has_align) { // features see the ALIGNED frame (ann.py:565)
-                p0 = rotate((p0 - c0) - dl, R);
-                if (type != IT_POSITION) {
-                    p1 = rotate((p1 - c0) - dl, R);
-                    p2 = rotate((p2 - c0) - dl, R);
-                    p3 = rotate((p3 - c0) - dl, R);
-                }
-            }
-            float v[3];
-            const int w = eval_item(type, p0, p1, p2, p3, v);
-            fbuf[col * FB_STRIDE + lane] = v[0];
-            if (w > 1) fbuf[(col + 1) * FB_STRIDE + lane] = v[1];
-            if (w > 2) fbuf[(col + 2) * FB_STRIDE + lane] = v[2];
-        }
-
-        // ---- 4. fused small MLP (ann.py:60-65): weights are wave-uniform scalar operands ------
-        if constexpr (MLPW > 0) {
-            float h[MLPW];
-            {
-                const auto wl = wpack + a.woff[0];
-#pragma unroll
-                for (int j = 0; j < MLPW; ++j) h[j] = wl[j];
-                const int K = a.dims[0];
-                for (int k = 0; k < K; ++k) {
-                    const float f = fbuf[k * FB_STRIDE + lane];
-                    const auto wr = wl + MLPW + k * MLPW;
-#pragma unroll
-                    for (int j = 0; j < MLPW; ++j) h[j] = fmaf(wr[j], f, h[j]);
-                }
-            }
-            for (int l = 1; l < a.n_layers; ++l) {
-                activate<MLPW, true>(a.act, h);
-                float g[MLPW];
-                const auto wl = wpack + a.woff[l];
-#pragma unroll
-                for (int j = 0; j < MLPW; ++j) g[j] = wl[j];
-                const int K = a.dims[l];
-#pragma unroll
-                for (int k = 0; k < MLPW; ++k) {
-                    if (k < K) {
-                        const auto wr = wl + MLPW + k * MLPW;
-#pragma unroll
-                        for (int j = 0; j < MLPW; ++j) g[j] = fmaf(wr[j], h[k], g[j]);
+                // unused entries of an item repeat its first atom: always four reads in one batch
+                V3 p0 = lds_atom(fr, i0), p1 = lds_atom(fr, i1);
+                V3 p2 = lds_atom(fr, i2), p3 = lds_atom(fr, i3);
+                if (has_align) { // features see the ALIGNED frame (ann.py:565)
+                    p0 = rotate((p0 - c0) - dl, R);
+                    if (type != IT_POSITION) {
+                        p1 = rotate((p1 - c0) - dl, R);
+                        p2 = rotate((p2 - c0) - dl, R);
+                        p3 = rotate((p3 - c0) - dl, R);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < MLPW; ++j) h[j] = g[j];
+                float v[3];
+                const int w = eval_item(type, p0, p1, p2, p3, v);
+                fbuf[col * FB_STRIDE + lane] = v[0];
+                if (w > 1) fbuf[(col + 1) * FB_STRIDE + lane] = v[1];
+                if (w > 2) fbuf[(col + 2) * FB_STRIDE + lane] = v[2];
             }
-#pragma unroll
-            for (int j = 0; j < MLPW; ++j)
-                if (j < a.out_cols) fbuf[j * FB_STRIDE + lane] = h[j];
-        }
 
-        // ---- 5. read-out: fbuf[col][frame] -> out[t*64 + frame][col], contiguous per wave ------
-        {
-            float* gdst = out + t * 64 * (long)a.out_cols;
-            const int n_valid = nfr * a.out_cols;
-            int f = ro_f0, c = ro_c0;
-            for (int e = lane; e < n_valid; e += 64) {
-                gdst[e] = fbuf[c * FB_STRIDE + f];
-                c += a.step_c;
-                f += a.step_f;
-                if (c >= a.out_cols) { c -= a.out_cols; ++f; }
+            // The atoms are dead from here on: start the next tile's LDS-DMA now, so that its HBM latency
+            // runs under the MLP and the stores of this tile.
+            if (t + t_step < n_tiles) stage_tile_dense(x, tile, t + t_step, a, lane);
+
+            if constexpr (NL > 0) {
+                // ---- 4. fused MLP on the fp32 MFMA, four blocks of 16 frames ------------------
+                const int ks0 = (a.dims[0] + 3) >> 2;
+                float* gout = out + (t * 64) * (long)a.out_cols;
+#pragma unroll 2
+                for (int fb = 0; fb < 4; ++fb) {
+                    f32x4 D[2];
+                    D[1] = wB[0][1];
+                    {   // layer 0: B operand from the staging buffer, k = 4 ks + q
+                        float bin[8];
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks)
+                            bin[ks] = ks < ks0 ? fbuf[(4 * ks + q4) * FB_STRIDE + 16 * fb + i16] : 0.f;
+#pragma unroll
+                        for (int ub = 0; ub < 2; ++ub) {
+                            if (ub == 0 || a.dims[1] > 16) {
+                                f32x4 acc = wB[0][ub];
+                                switch (ks0) {
+                                case 1: acc = mfma_chain<1>(wA[0][ub], 0, bin, acc); break;
+                                case 2: acc = mfma_chain<2>(wA[0][ub], 0, bin, acc); break;
+                                case 3: acc = mfma_chain<3>(wA[0][ub], 0, bin, acc); break;
+                                case 4: acc = mfma_chain<4>(wA[0][ub], 0, bin, acc); break;
+                                case 5: acc = mfma_chain<5>(wA[0][ub], 0, bin, acc); break;
+                                case 6: acc = mfma_chain<6>(wA[0][ub], 0, bin, acc); break;
+                                case 7: acc = mfma_chain<7>(wA[0][ub], 0, bin, acc); break;
+                                default: acc = mfma_chain<8>(wA[0][ub], 0, bin, acc); break;
+                                }
+                                D[ub] = acc;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int l = 1; l < NL; ++l) {
+                        if (a.ablate & 4) break;
+                        const bool wide_in = a.dims[l] > 16;
+                        float h0[4] = {D[0][0], D[0][1], D[0][2], D[0][3]};
+                        float h1[4] = {D[1][0], D[1][1], D[1][2], D[1][3]};
+                        activate<4, true>(a.act, h0);
+                        if (wide_in) activate<4, true>(a.act, h1);
+#pragma unroll
+                        for (int ub = 0; ub < 2; ++ub) {
+                            f32x4 acc = wB[l][ub];
+                            if (ub == 0 || a.dims[l + 1] > 16) {
+                                acc = mfma_chain<4>(wA[l][ub], 0, h0, acc);
+                                if (wide_in) acc = mfma_chain<4>(wA[l][ub], 4, h1, acc);
+                            }
+                            D[ub] = acc;
+                        }
+                    }
+                    // D[ub][r] = out[frame 16 fb + i16][16 ub + 4 q + r]
+                    const int frame = 16 * fb + i16;
+                    if (frame < nfr) {
+                        float* orow = gout + (long)frame * a.out_cols;
+#pragma unroll
+                        for (int ub = 0; ub < 2; ++ub) {
+                            const int u0 = 16 * ub + 4 * q4;
+                            if (u0 + 3 < a.out_cols && a.out_vec4) {
+                                *(f32x4*)(orow + u0) = D[ub];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (u0 + r < a.out_cols) orow[u0 + r] = D[ub][r];
+                            }
+                        }
+                    }
+                }
+            } else {
+                // ---- 5. read-out: fbuf[col][frame] -> out[t*64 + frame][col], contiguous per wave
+                float* gdst = out + t * 64 * (long)a.out_cols;
+                const int n_valid = nfr * a.out_cols;
+                int f = ro_f0, c = ro_c0;
+                for (int e = lane; e < n_valid; e += 64) {
+                    gdst[e] = fbuf[c * FB_STRIDE + f];
+                    c += a.step_c;
+                    f += a.step_f;
+                    if (c >= a.out_cols) { c -= a.out_cols; ++f; }
+                }
             }
         }
     }
@@ -477,9 +603,6 @@ struct MlpArgs {
     int in_stride;                // row stride of the input features (floats)
 };
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ unsigned short f2bf(float f) { // round-to-nearest-even, NaN kept
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
@@ -580,9 +703,7 @@ struct PackArgs {
     const float* b[MOLANN_MAX_LAYERS];
     int dims[MOLANN_MAX_LAYERS + 1];
     int n_layers;
-    // lane-kernel layout
-    int mlpw;
-    int woff[MOLANN_MAX_LAYERS];
+    int fused;      // also write the lane kernel's per-lane MFMA fragments
     // mfma layout
     int kp[MOLANN_MAX_LAYERS];
     int jp[MOLANN_MAX_LAYERS];
@@ -590,19 +711,28 @@ struct PackArgs {
     int bf16;
 };
 
-// lane layout, layer l: bias[mlpw] then Wt[k][mlpw]  (transposed, zero padded)
+// Per-lane MFMA fragments of the fused MLP (frames_lane_kernel): for layer l, unit block ub, k-step ks,
+// lane (i = lane&15, q = lane>>4):  A = W_l[16ub + i][k],  k = 4ks + q for layer 0 and
+// k = 16(ks>>2) + 4q + (ks&3) for the following layers; then the bias fragments b_l[16ub + 4q + r].
 __global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
-    const int l = blockIdx.y;
-    const int K = p.dims[l], J = p.dims[l + 1], W = p.mlpw;
-    float* d = dst + p.woff[l];
-    const int total = W + K * W;
+    const int NL = p.n_layers;
+    const int total = NL * 1024 + NL * 512;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        if (e < W) {
-            d[e] = e < J ? p.b[l][e] : 0.f;
+        const int lane = e & 63, i = lane & 15, q = lane >> 4;
+        float v = 0.f;
+        if (e < NL * 1024) {
+            const int ks = (e >> 6) & 7, ub = (e >> 9) & 1, l = e >> 10;
+            const int K = p.dims[l], J = p.dims[l + 1];
+            const int j = 16 * ub + i;
+            const int k = l == 0 ? 4 * ks + q : 16 * (ks >> 2) + 4 * q + (ks & 3);
+            if (j < J && k < K) v = p.W[l][(long)j * K + k];
         } else {
-            const int k = (e - W) / W, j = (e - W) - k * W;
-            d[e] = j < J ? p.W[l][(long)j * K + k] : 0.f;
+            const int f = e - NL * 1024;
+            const int r = (f >> 6) & 3, ub = (f >> 8) & 1, l = f >> 9;
+            const int j = 16 * ub + 4 * q + r;
+            if (j < p.dims[l + 1]) v = p.b[l][j];
         }
+        dst[e] = v;
     }
 }
 
@@ -673,7 +803,6 @@ struct molann_plan {
     int out_dim;
     int family;        // 0 lane-per-frame, 1 wave-per-frame
     bool fused_mlp;    // lane kernel runs the MLP itself
-    int mlpw;          // register width of the fused MLP (8/16/32)
     // device memory (one allocation)
     unsigned char* blob;
     int* d_align_idx;
@@ -684,12 +813,11 @@ struct molann_plan {
     void* d_wmfma;     // mfma layout
     float* d_work;     // feature chunk [work_frames][d_feat]
     long work_frames;
-    int woff[MOLANN_MAX_LAYERS];
     int kp[MOLANN_MAX_LAYERS], jp[MOLANN_MAX_LAYERS];
     long moff[MOLANN_MAX_LAYERS];
     int mlp_ld, mlp_lds_per_wave;
-    // lane kernel geometry
-    int lane_lds_per_wave, lane_fbuf_off, lane_wpb;
+    // lane kernel geometry: [0] feature mode (tile + staging columns), [1] align-out mode (tile only)
+    struct LaneGeom { int lds_per_wave, fbuf_off, wpb, ok; } geom[2];
     bool mlp_packed;
     char last_info[256];
 };
@@ -702,15 +830,14 @@ namespace {
         if (_e != hipSuccess) return (int)_e; \
     } while (0)
 
-int lane_geometry(molann_plan* p, int cols_needed) {
-    const int tile_bytes = 64 * p->n_inp * 12;
+// waves never share LDS, so the block size is free: take the one that packs most waves into the CU's
+// 160 KiB (blocks <= 64 KiB: the LDS-DMA destination offset is 16 bits), larger block on ties
+void lane_geometry(molann_plan::LaneGeom& g, int tile_bytes, int cols_needed) {
     const int tile_pad = ceil_to(tile_bytes, 16);
     const int fbuf_bytes = ceil_to(cols_needed * FB_STRIDE * 4, 16);
-    p->lane_fbuf_off = tile_pad;
-    p->lane_lds_per_wave = tile_pad + fbuf_bytes;
-    // waves never share LDS, so the block size is free: take the one that packs most waves into the
-    // CU's 160 KiB (blocks <= 64 KiB: the LDS-DMA destination offset is 16 bits), larger block on ties
-    const long L = p->lane_lds_per_wave;
+    g.fbuf_off = tile_pad;
+    g.lds_per_wave = tile_pad + fbuf_bytes;
+    const long L = g.lds_per_wave;
     int best = 0, best_waves = 0;
     for (int wpb = 4; wpb >= 1; --wpb) {
         if (wpb * L > 65536) continue;
@@ -718,8 +845,8 @@ int lane_geometry(molann_plan* p, int cols_needed) {
         if (waves > 32) waves = 32;
         if (waves > best_waves) { best_waves = (int)waves; best = wpb; }
     }
-    p->lane_wpb = best;
-    return (best >= 1 && best_waves >= 4) ? 0 : -1; // fewer than 4 waves per CU: use the wave-per-frame kernel
+    g.wpb = best;
+    g.ok = (best >= 1 && best_waves >= 4) ? 1 : 0; // fewer than 4 waves per CU: use the wave-per-frame kernel
 }
 
 int validate_desc(const molann_plan_desc* d) {
@@ -778,14 +905,17 @@ void fill_pre_args(const molann_plan* p, PreArgs& a, long n_frames, int mode, in
     a.out_cols = out_cols > 0 ? out_cols : 1;
     a.step_f = 64 / a.out_cols;
     a.step_c = 64 % a.out_cols;
-    a.lds_per_wave = p->lane_lds_per_wave;
-    a.fbuf_off = p->lane_fbuf_off;
+    const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
+    a.lds_per_wave = g.lds_per_wave;
+    a.fbuf_off = g.fbuf_off;
     a.x_wide = (((uintptr_t)x) & 15) == 0;
     a.out_wide = (((uintptr_t)out) & 15) == 0;
     a.n_layers = with_mlp ? p->n_layers : 0;
     a.act = p->act;
     for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
-    for (int i = 0; i < p->n_layers; ++i) a.woff[i] = p->woff[i];
+    a.out_vec4 = (a.out_wide && (a.out_cols & 3) == 0) ? 1 : 0;
+    const char* dbg = getenv("MOLANN_DEBUG_ABLATE");
+    a.ablate = dbg ? atoi(dbg) : 0;
 }
 
 // preprocessing (align / features / fused forward) for n_frames starting at x -> out
@@ -794,26 +924,29 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
     const int out_cols = mode == 1 ? 0 : (with_mlp ? p->out_dim : p->d_feat);
     PreArgs a;
     fill_pre_args(p, a, n_frames, mode, out_cols, with_mlp, x, out);
-    if (p->family == 0) {
-        const int wpb = p->lane_wpb;
+    const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
+    if (g.ok) {
+        const int wpb = g.wpb;
         const long n_tiles = (n_frames + 63) / 64;
-        int bpc = (int)(163840 / ((long)wpb * p->lane_lds_per_wave));
+        int bpc = (int)(163840 / ((long)wpb * g.lds_per_wave));
         if (bpc < 1) bpc = 1;
         if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
         const int grid = grid_for(p, n_tiles, wpb, bpc);
-        const size_t lds = (size_t)wpb * p->lane_lds_per_wave;
+        const size_t lds = (size_t)wpb * g.lds_per_wave;
         const dim3 block(64 * wpb);
-        const int w = with_mlp ? p->mlpw : 0;
-#define LAUNCH_LANE(W)                                                                                          \
-    hipLaunchKernelGGL((frames_lane_kernel<W>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
+        const int w = with_mlp ? p->n_layers : 0;
+#define LAUNCH_LANE(W, AO)                                                                                      \
+    hipLaunchKernelGGL((frames_lane_kernel<W, AO>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
                        p->d_ref64, p->d_items, p->d_wlane, a)
-        if (w == 0) LAUNCH_LANE(0);
-        else if (w == 8) LAUNCH_LANE(8);
-        else if (w == 16) LAUNCH_LANE(16);
-        else LAUNCH_LANE(32);
+        if (mode == 1) LAUNCH_LANE(0, true);
+        else if (w == 0) LAUNCH_LANE(0, false);
+        else if (w == 1) LAUNCH_LANE(1, false);
+        else if (w == 2) LAUNCH_LANE(2, false);
+        else if (w == 3) LAUNCH_LANE(3, false);
+        else LAUNCH_LANE(4, false);
 #undef LAUNCH_LANE
-        snprintf(p->last_info, sizeof(p->last_info), "frames_lane_kernel<%d> grid=%d block=%d lds=%zu mode=%d", w, grid,
-                 64 * wpb, lds, mode);
+        snprintf(p->last_info, sizeof(p->last_info), "frames_lane_kernel<%d,%s> grid=%d block=%d lds=%zu", w,
+                 mode == 1 ? "align_out" : "features", grid, 64 * wpb, lds);
     } else {
         const int wpb = 4;
         const int grid = grid_for(p, n_frames, wpb, 8);
@@ -938,11 +1071,16 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     for (int i = 1; i <= d->n_layers; ++i) max_w = std::max(max_w, d->layer_dims[i]);
     const bool cheap_act = d->activation != MOLANN_ACT_ELU && d->activation != MOLANN_ACT_SOFTPLUS &&
                            d->activation != MOLANN_ACT_GELU;
-    const bool small_mlp = d->n_layers > 0 && max_w <= LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
-    p->mlpw = max_w <= 8 ? 8 : (max_w <= 16 ? 16 : 32);
-    const int cols_needed = std::max(1, std::max(d_feat, small_mlp ? p->out_dim : 0));
-    p->family = 1;
-    if (cols_needed <= LANE_MAX_COLS && lane_geometry(p, cols_needed) == 0) p->family = 0;
+    const bool small_mlp = d->n_layers > 0 && d->n_layers <= LANE_MLP_MAX_LAYERS && max_w <= LANE_MLP_MAX_WIDTH &&
+                           d_feat <= LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
+    const int cols_needed = std::max(1, small_mlp ? ceil_to(d_feat, 4) : d_feat);
+    memset(p->geom, 0, sizeof(p->geom));
+    const bool lane_tables_fit = d->n_align <= 64 && (long)d->n_inp * 768 <= 65536;
+    if (p->n_items > 0 && lane_tables_fit && cols_needed <= LANE_MAX_COLS)
+        lane_geometry(p->geom[0], 64 * d->n_inp * 12, cols_needed);
+    if (d->n_align > 0 && lane_tables_fit) lane_geometry(p->geom[1], 64 * d->n_inp * 12, 1);
+    // the family names the kernel that serves the plan's main product (features if it has any)
+    p->family = (p->n_items > 0 ? p->geom[0].ok : p->geom[1].ok) ? 0 : 1;
     p->fused_mlp = (p->family == 0) && small_mlp && d->n_features > 0;
 
     // ---- device blob ----------------------------------------------------------------------------
@@ -952,12 +1090,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const size_t o_ref = carve(sizeof(float) * (3 * (size_t)d->n_align + 8));
     const size_t o_ref64 = carve(sizeof(double) * (3 * (size_t)d->n_align + 8));
     const size_t o_items = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
+
     size_t lane_floats = 0;
-    if (p->fused_mlp)
-        for (int l = 0; l < d->n_layers; ++l) {
-            p->woff[l] = (int)lane_floats;
-            lane_floats += (size_t)p->mlpw + (size_t)p->dims[l] * p->mlpw;
-        }
+    if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512);
     const size_t o_wlane = carve(sizeof(float) * std::max<size_t>(1, lane_floats));
     size_t mfma_bytes = 0;
     const bool bf16 = d->mlp_precision == MOLANN_MLP_BF16;
@@ -1039,6 +1174,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     }
     if (e == hipSuccess && !items.empty())
         e = hipMemcpy(p->d_items, items.data(), sizeof(ItemDev) * items.size(), hipMemcpyHostToDevice);
+
     if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
     *out_plan = p;
@@ -1079,13 +1215,12 @@ int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* c
     for (int l = 0; l < p->n_layers; ++l) {
         if (!W[l] || !b[l]) return MOLANN_E_NULL;
         a.W[l] = W[l]; a.b[l] = b[l];
-        a.woff[l] = p->woff[l];
         a.kp[l] = p->kp[l]; a.jp[l] = p->jp[l]; a.moff[l] = p->moff[l];
     }
-    a.mlpw = p->mlpw;
+    a.fused = p->fused_mlp ? 1 : 0;
     a.bf16 = p->mlp_prec == MOLANN_MLP_BF16;
     if (p->fused_mlp)
-        hipLaunchKernelGGL(pack_lane_kernel, dim3(4, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
+        hipLaunchKernelGGL(pack_lane_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
     // the MFMA copy serves molann_mlp_packed_f32 and the unfused forward
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(64, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wmfma, a);
     const hipError_t e = hipGetLastError();

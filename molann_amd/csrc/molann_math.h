@@ -44,6 +44,15 @@ MOLANN_HD float fast_rcp(float x) {
     return 1.0f / x;
 #endif
 }
+MOLANN_HD float fast_rsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+// sqrt(x) for x >= 0 as x * rsq(x) (1-2 ulp), exact 0 at 0 like sqrtf
+MOLANN_HD float fast_sqrt(float x) { return x > 0.0f ? x * fast_rsq(x) : (x == 0.0f ? 0.0f : sqrtf(x)); }
 MOLANN_HD float fast_exp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __expf(x);
@@ -56,16 +65,15 @@ MOLANN_HD float fast_exp(float x) {
 // bond length |x2 - x1| (ann.py:335-336)
 MOLANN_HD float feat_bond(V3 a0, V3 a1) {
     V3 r = a1 - a0;
-    return sqrtf(dot(r, r));
+    return fast_sqrt(dot(r, r));
 }
 
 // cosine of the angle at the SECOND atom (ann.py:324-328); no clamp, as in the reference
 MOLANN_HD float feat_angle_cos(V3 a0, V3 a1, V3 a2) {
     V3 r21 = a0 - a1;
     V3 r23 = a2 - a1;
-    float l21 = sqrtf(dot(r21, r21));
-    float l23 = sqrtf(dot(r23, r23));
-    return dot(r21, r23) / (l21 * l23);
+    // dot / (|r21| |r23|) with one reciprocal square root of the product of the squared lengths
+    return dot(r21, r23) * fast_rsq(dot(r21, r21) * dot(r23, r23));
 }
 
 // unnormalised (cos, sin) of the dihedral 1-2-3-4 (ann.py:339-345)
@@ -76,7 +84,7 @@ MOLANN_HD void feat_dihedral_raw(V3 a0, V3 a1, V3 a2, V3 a3, float& c, float& s)
     V3 n1 = cross(r12, r23);
     V3 n2 = cross(r23, r34);
     c = dot(n1, n2);
-    s = dot(n1, r34) * sqrtf(dot(r23, r23));
+    s = dot(n1, r34) * fast_sqrt(dot(r23, r23));
 }
 
 // One item of the feature table on up to four atoms; writes 1..3 values, returns how many.
@@ -94,9 +102,9 @@ MOLANN_HD int eval_item(int type, V3 a0, V3 a1, V3 a2, V3 a3, float (&out)[3]) {
     case IT_DIHEDRAL_CS: {
         float c, s;
         feat_dihedral_raw(a0, a1, a2, a3, c, s);
-        float radius = sqrtf(fmaf(c, c, s * s)); // ann.py:346
-        out[0] = c / radius;                     // ann.py:351 cos first, then sin
-        out[1] = s / radius;
+        const float inv_radius = fast_rsq(fmaf(c, c, s * s)); // 1 / radius, ann.py:346
+        out[0] = c * inv_radius;                              // ann.py:351 cos first, then sin
+        out[1] = s * inv_radius;
         return 2;
     }
     case IT_DIHEDRAL_VAL: {
@@ -119,15 +127,16 @@ MOLANN_HD int item_atoms(int type) {
 }
 
 // ---- activations ------------------------------------------------------------------------------
-// tanh to a few ulp: odd polynomial below 1/8 (no cancellation), (1-t)/(1+t), t = e^{-2|x|} above.
+// tanh(x) = 1 - 2 / (1 + e^{2x}): five instructions, two of them transcendental.  Absolute error
+// <= ~1.5e-7 everywhere (the 1 - 2r cancellation near 0 costs relative, not absolute, accuracy; the
+// parity bar of this path is absolute, 1e-5).  +-inf and NaN behave like tanhf.
 MOLANN_HD float act_tanh(float x) {
-    float ax = fabsf(x);
-    float t = fast_exp(-2.0f * ax);
-    float big = (1.0f - t) * fast_rcp(1.0f + t);
-    float x2 = x * x;
-    float poly = fmaf(x2, fmaf(x2, fmaf(x2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
-    float r = (ax < 0.125f) ? ax * poly : big;
-    return copysignf(r, x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float t = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f); // e^{2x} = 2^{2x log2 e}
+#else
+    const float t = exp2f(x * 2.88539008177792681472f);
+#endif
+    return fmaf(-2.0f, fast_rcp(1.0f + t), 1.0f);
 }
 
 MOLANN_HD float act_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
@@ -166,12 +175,17 @@ MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) {
     double fro2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) fro2 = fma(H[i], H[i], fro2);
-    if (!(fro2 > 1e-60) || !(fro2 < 1e60)) { // zero / non-finite covariance: no rotation
+    if (!(fro2 > 1e-30) || !(fro2 < 1e30)) { // zero / non-finite covariance: no rotation
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
         return;
     }
-    const double s = 1.0 / sqrt(fro2); // scale so that |h|_F = 1: the rotation does not depend on it
+    // scale so that |h|_F ~= 1: the rotation does not depend on the scale, so an fp32 rsqrt is enough
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double s = (double)__builtin_amdgcn_rsqf((float)fro2);
+#else
+    const double s = (double)(1.0f / sqrtf((float)fro2));
+#endif
     const double hxx = H[0] * s, hxy = H[1] * s, hxz = H[2] * s;
     const double hyx = H[3] * s, hyy = H[4] * s, hyz = H[5] * s;
     const double hzx = H[6] * s, hzy = H[7] * s, hzz = H[8] * s;
@@ -241,12 +255,14 @@ MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) {
     if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
     if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
     const double n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
-    if (!(n2 > 0.0) || !(n2 < 1e300)) { // K - lam I numerically zero: degenerate input
+    if (!(n2 > 1e-30) || !(n2 < 1e30)) { // K - lam I numerically zero: degenerate input
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
         return;
     }
-    const double inv = 1.0 / n2;
+    // 1/n2: fp32 reciprocal seed + one Newton step in fp64 (relative error ~1e-14)
+    double inv = (double)fast_rcp((float)n2);
+    inv = inv * (2.0 - n2 * inv);
     const double ww = q0 * q0 * inv, xx = q1 * q1 * inv, yy = q2 * q2 * inv, zz = q3 * q3 * inv;
     const double wx = q0 * q1 * inv, wy = q0 * q2 * inv, wz = q0 * q3 * inv;
     const double xy = q1 * q2 * inv, xz = q1 * q3 * inv, yz = q2 * q3 * inv;

@@ -205,3 +205,21 @@ def get_workload(name):
 
 def workload_names():
     return list(_FACTORIES)
+
+
+def build_model(w, device=None, seed=0):
+    """The product model (molann_amd.ann modules) of a workload; input group = all atoms."""
+    from .ann import AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn
+    from .atomgroup import Universe
+    from .feature import Feature
+    u = Universe(w.ref_xyz)
+    input_ag = u.atoms
+    alayer = AlignmentLayer(u.atoms_by_number(w.align), input_ag) if w.align is not None else None
+    feats = [Feature("f%d" % i, TYPE_NAMES[t], u.atoms_by_number(atoms)) for i, (t, atoms) in enumerate(w.features)]
+    pp = PreprocessingANN(alayer, FeatureLayer(feats, input_ag, w.use_angle_value))
+    if not w.mlp_dims:
+        model = pp
+    else:
+        torch.manual_seed(seed)
+        model = MolANN(pp, create_sequential_nn(w.mlp_dims), mlp_precision=("bf16" if w.mlp_dtype == "bf16" else "f32"))
+    return model.to(device) if device is not None else model

@@ -50,17 +50,7 @@ def build_modules(case, device=None, mlp_precision="f32"):
 
 def workload_model(w, device=None, seed=0):
     """The product model of a BASELINE workload (input group = all atoms)."""
-    u = Universe(w.ref_xyz)
-    input_ag = u.atoms
-    alayer = AlignmentLayer(u.atoms_by_number(w.align), input_ag) if w.align is not None else None
-    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number(atoms)) for i, (t, atoms) in enumerate(w.features)]
-    pp = PreprocessingANN(alayer, FeatureLayer(feats, input_ag, w.use_angle_value))
-    if not w.mlp_dims:
-        model = pp
-    else:
-        torch.manual_seed(seed)
-        model = MolANN(pp, create_sequential_nn(w.mlp_dims), mlp_precision=("bf16" if w.mlp_dtype == "bf16" else "f32"))
-    return model.to(device) if device is not None else model
+    return wl.build_model(w, device, seed)
 
 
 def oracle_for_workload(w, model, x, dtype=torch.float32):
