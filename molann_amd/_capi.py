@@ -188,9 +188,10 @@ class Plan(object):
         _check(lib().molann_plan_update_mlp(self._handle, W, B, self._stream()), "molann_plan_update_mlp")
 
     def _run(self, fn_name, x, out, n):
-        fn = getattr(lib(), fn_name)
-        _check(fn(self._handle, ctypes.c_void_p(x.data_ptr()), int(n), ctypes.c_void_p(out.data_ptr()), self._stream()),
-               fn_name)
+        code = getattr(_lib, fn_name)(self._handle, x.data_ptr(), n, out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, fn_name)
         return out
 
     def align(self, x, out):

@@ -131,6 +131,7 @@ class _PlanOwner(object):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_plan_cache", None)
+        state.pop("_fast", None)
         return state
 
     def __deepcopy__(self, memo):
@@ -139,7 +140,7 @@ class _PlanOwner(object):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k != "_plan_cache":
+            if k not in ("_plan_cache", "_fast"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
@@ -351,41 +352,69 @@ class MolANN(_PlanOwner, torch.nn.Module):
     def get_preprocessing_layer(self):
         return self.preprocessing_layer
 
-    def forward(self, x):
+    def _fast_state(self, x):
+        """Everything about this model that does not change from call to call (which modules it is made
+        of, the recognised MLP, the plan), rebuilt only when the module tree or the device changes."""
         pp = self.preprocessing_layer
-        rec = recognise_mlp(self.ann_layers)
-        if rec is None or not (isinstance(pp, PreprocessingANN) and pp._fusable()):
-            return self.ann_layers(pp(x))
-        linears, act = rec
-        fl = pp.feature_layer
-        al = pp.align_layer if isinstance(pp.align_layer, AlignmentLayer) else None
+        nn = self.ann_layers
+        fl = getattr(pp, "feature_layer", None)
+        al = getattr(pp, "align_layer", None)
+        sig = (id(pp), id(nn), id(fl), id(al), len(getattr(nn, "_modules", ())), x.device.index, self.mlp_precision)
+        st = self.__dict__.get("_fast")
+        if st is not None and st["sig"] == sig:
+            return st
+        rec = recognise_mlp(nn)
+        st = {"sig": sig, "fused": False}
+        if rec is not None and isinstance(pp, PreprocessingANN) and pp._fusable():
+            linears, act = rec
+            al = al if isinstance(al, AlignmentLayer) else None
+            spec, uav = _feature_spec(fl)
+            dims = [linears[0].in_features] + [lin.out_features for lin in linears]
+            assert dims[0] == fl.output_dimension(), \
+                'ann_layers expects %d inputs but the feature layer produces %d' % (dims[0], fl.output_dimension())
+
+            def build():
+                return _capi.Plan(fl.input_atom_num,
+                                  align_idx=al._local_align_atom_indices if al is not None else None,
+                                  ref_x=al.ref_x if al is not None else None,
+                                  features=spec, use_angle_value=uav, layer_dims=dims, activation=act,
+                                  mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
+
+            entry = _get_entry(self, x, ("forward", tuple(dims), act, self.mlp_precision), build)
+            st.update(fused=True, linears=linears, al=al, fl=fl, out_dim=dims[-1], entry=entry,
+                      params=[p for lin in linears for p in (lin.weight, lin.bias)])
+        self.__dict__["_fast"] = st
+        return st
+
+    def forward(self, x):
+        assert isinstance(x, torch.Tensor), 'Input x is not a torch tensor'
+        st = self._fast_state(x) if x.is_cuda else None
+        if st is None or not st["fused"]:
+            if recognise_mlp(self.ann_layers) is None or not (isinstance(self.preprocessing_layer, PreprocessingANN)
+                                                              and self.preprocessing_layer._fusable()):
+                return self.ann_layers(self.preprocessing_layer(x))
+            _check_input(x, self.preprocessing_layer.feature_layer.input_atom_num)
+            _device_input(x)          # raises: not a device tensor
+        al, fl, entry = st["al"], st["fl"], st["entry"]
         if al is not None:
             _check_input(x, al.input_atom_num)
         _check_input(x, fl.input_atom_num)
-        x = _device_input(x, grad_sources=[p for lin in linears for p in (lin.weight, lin.bias)])
-        spec, uav = _feature_spec(fl)
-        dims = [linears[0].in_features] + [lin.out_features for lin in linears]
-        assert dims[0] == fl.output_dimension(), \
-            'ann_layers expects %d inputs but the feature layer produces %d' % (dims[0], fl.output_dimension())
-
-        def build():
-            return _capi.Plan(fl.input_atom_num,
-                              align_idx=al._local_align_atom_indices if al is not None else None,
-                              ref_x=al.ref_x if al is not None else None,
-                              features=spec, use_angle_value=uav, layer_dims=dims, activation=act,
-                              mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
-
-        entry = _get_entry(self, x, ("forward", tuple(dims), act, self.mlp_precision), build)
-        out = torch.empty((x.shape[0], dims[-1]), dtype=torch.float32, device=x.device)
+        x = _device_input(x, grad_sources=st["params"])
+        out = torch.empty((x.shape[0], st["out_dim"]), dtype=torch.float32, device=x.device)
         if x.shape[0] == 0:
             return out
-        for lin in linears:
-            if lin.weight.device != x.device or lin.weight.dtype != torch.float32:
-                raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" %
-                                   (x.device, lin.weight.dtype, lin.weight.device))
-        with torch.cuda.device(x.device):
+        w0 = st["linears"][0].weight
+        if w0.device != x.device or w0.dtype != torch.float32:
+            raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))
+        if x.device.index == torch.cuda.current_device():
             if al is not None:
                 entry.sync_ref(_device_buffer(al.ref_x, x))
-            entry.sync_mlp(linears)
+            entry.sync_mlp(st["linears"])
             entry.plan.forward_packed(x, out)
+        else:
+            with torch.cuda.device(x.device):
+                if al is not None:
+                    entry.sync_ref(_device_buffer(al.ref_x, x))
+                entry.sync_mlp(st["linears"])
+                entry.plan.forward_packed(x, out)
         return out

@@ -1,0 +1,182 @@
+"""Host logic of the module API (no GPU): constructors, index spaces, dims, error behaviour and
+state_dict keys, checked against what the reference itself reports (tests/golden)."""
+
+import copy
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from build_util import build_modules, universe_for
+from golden_util import Case, case_names, load_meta
+from molann_amd import workloads as wl
+from molann_amd.ann import (AlignmentLayer, FeatureLayer, FeatureMap, MolANN, PreprocessingANN, create_sequential_nn,
+                            recognise_mlp)
+from molann_amd.atomgroup import AtomGroup, Universe
+from molann_amd.feature import Feature, FeatureFileReader
+
+META = load_meta()
+U = Universe(wl.ALA_DIPEPTIDE_XYZ)
+ALL22 = list(range(1, 23))
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_constructor_index_spaces_match_reference(name):
+    """_local_align_atom_indices / _local_atom_indices / dims / ref_x equal the reference's."""
+    c = Case(name)
+    model = build_modules(c)
+    pp = model if c.kind == "features" else (model.preprocessing_layer if c.kind == "forward" else None)
+    al = model if c.kind == "align" else pp.align_layer
+    if c.has_align:
+        assert al._local_align_atom_indices == c.align_local
+        assert al.input_atom_indices == c.input_ix and al.input_atom_num == c.n_inp
+        assert torch.equal(al.ref_x, c.ref_x)                # centred exactly as the reference centres it
+    if pp is not None:
+        fl = pp.feature_layer
+        assert [fm._local_atom_indices for fm in fl.feature_map_list] == [idx for _, idx in c.features]
+        assert [fm.dim() for fm in fl.feature_map_list] == c.feat_dims
+        assert fl.output_dimension() == c.feature_dim == pp.output_dimension()
+    if c.kind == "forward" and c.state_dict_keys is not None:
+        assert list(model.state_dict().keys()) == c.state_dict_keys
+
+
+def _err(fn):
+    try:
+        fn()
+        return "none"
+    except BaseException as e:  # noqa: BLE001
+        return type(e).__name__
+
+
+def test_error_types_match_reference_table():
+    pdb = wl.ALA_DIPEPTIDE_XYZ
+    input_ag = U.atoms_by_number(ALL22)
+    al = AlignmentLayer(U.atoms_by_number([1, 2, 5]), input_ag)
+    fl = FeatureLayer([Feature("b", "bond", U.atoms_by_number([5, 6]))], input_ag)
+    fmap = FeatureMap(Feature("b", "bond", U.atoms_by_number([5, 6])), input_ag)
+    x22 = torch.from_numpy(pdb)
+    got = {
+        "align_not_tensor": _err(lambda: al(pdb)),
+        "align_2d_input": _err(lambda: al(x22)),
+        "align_wrong_natoms": _err(lambda: al(x22[:21].unsqueeze(0))),
+        "align_wrong_last": _err(lambda: al(torch.zeros(4, 22, 2))),
+        "flayer_not_tensor": _err(lambda: fl(pdb)),
+        "flayer_2d_input": _err(lambda: fl(x22)),
+        "flayer_wrong_natoms": _err(lambda: fl(x22[:21].unsqueeze(0))),
+        "fmap_wrong_natoms": _err(lambda: fmap(x22[:21].unsqueeze(0))),
+        "align_atom_not_in_input": _err(lambda: AlignmentLayer(U.atoms_by_number([1, 2, 5]), U.atoms_by_number([1, 2, 3]))),
+        "feature_atom_not_in_input": _err(lambda: FeatureMap(Feature("b", "bond", U.atoms_by_number([5, 6])),
+                                                             U.atoms_by_number([1, 2, 3, 4, 5]))),
+        "flayer_empty_list": _err(lambda: FeatureLayer([], input_ag)),
+        "nn_one_dim": _err(lambda: create_sequential_nn([10])),
+        "feature_unknown_type": _err(lambda: Feature("q", "torsion", U.atoms_by_number([1, 2]))),
+        "feature_repeated_atoms": _err(lambda: Feature("q", "bond", U.atoms_by_number([1, 1]))),
+        "feature_bond_3atoms": _err(lambda: Feature("q", "bond", U.atoms_by_number([1, 2, 3]))),
+        "feature_angle_2atoms": _err(lambda: Feature("q", "angle", U.atoms_by_number([1, 2]))),
+        "feature_dihedral_3atoms": _err(lambda: Feature("q", "dihedral", U.atoms_by_number([1, 2, 3]))),
+    }
+    for key, want in META["errors"].items():
+        if key.startswith("empty_batch"):
+            continue                      # legal in the reference; here it needs a device tensor (GPU test)
+        assert got[key] == want, (key, got[key], want)
+
+
+def test_no_cpu_fallback():
+    """A well-formed CPU tensor is refused: the product has no CPU path."""
+    al = AlignmentLayer(U.atoms_by_number([1, 2, 5]), U.atoms)
+    fl = FeatureLayer([Feature("b", "bond", U.atoms_by_number([5, 6]))], U.atoms)
+    x = torch.from_numpy(wl.ALA_DIPEPTIDE_XYZ).unsqueeze(0)
+    for m in (al, fl, PreprocessingANN(al, fl), MolANN(PreprocessingANN(None, fl), create_sequential_nn([1, 4, 2]))):
+        with pytest.raises(RuntimeError):
+            with torch.no_grad():
+                m(x)
+
+
+def test_sequential_names_and_state_dict_keys():
+    nn = create_sequential_nn([3, 5, 4, 2])
+    assert list(nn._modules.keys()) == META["sequential_module_names"]
+    acts = [m for k, m in nn._modules.items() if k.startswith("activation")]
+    assert acts[0] is acts[1]                                      # one shared activation object (ann.py:64)
+    al = AlignmentLayer(U.atoms_by_number([1, 2, 5]), U.atoms)
+    fl = FeatureLayer([Feature("b", "bond", U.atoms_by_number([5, 6]))], U.atoms)
+    model = MolANN(PreprocessingANN(al, fl), create_sequential_nn([1, 4, 2]))
+    assert list(model.state_dict().keys()) == META["molann_state_dict_keys"]
+    assert model.get_preprocessing_layer() is model.preprocessing_layer
+    assert isinstance(PreprocessingANN(None, fl).align_layer, torch.nn.Identity)
+
+
+def test_recognise_mlp():
+    lin, act = recognise_mlp(create_sequential_nn([6, 32, 8]))
+    assert [l.out_features for l in lin] == [32, 8] and act == 0
+    assert recognise_mlp(create_sequential_nn([6, 8], activation=torch.nn.ReLU()))[1] == 3   # single layer: identity
+    assert recognise_mlp(create_sequential_nn([6, 8, 2], activation=torch.nn.ReLU()))[1] == 1
+    assert recognise_mlp(create_sequential_nn([6, 8, 2], activation=torch.nn.ELU(alpha=0.5))) is None
+    assert recognise_mlp(create_sequential_nn([6, 8, 2], activation=torch.nn.Hardtanh())) is None
+    assert recognise_mlp(torch.nn.Linear(3, 2)) is None
+    seq = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    assert recognise_mlp(seq) is None                              # widths do not chain
+
+
+def test_modules_copy_and_pickle_without_plans():
+    c = Case("molann_C3")
+    model = build_modules(c)
+    model._plans()["dummy"] = object()                             # stands for a device plan
+    m2 = copy.deepcopy(model)
+    assert "dummy" not in m2._plans() and list(m2.state_dict().keys()) == list(model.state_dict().keys())
+    buf = io.BytesIO()
+    del model._plans()["dummy"]
+    torch.save(model.state_dict(), buf)
+    buf.seek(0)
+    m2.load_state_dict(torch.load(buf, weights_only=True))
+    m3 = pickle.loads(pickle.dumps(model))
+    assert torch.equal(m3.preprocessing_layer.align_layer.ref_x, model.preprocessing_layer.align_layer.ref_x)
+
+
+def test_atomgroup_protocol_and_universe_selection(tmp_path):
+    ag = U.atoms_by_number([5, 2]) + U.atoms_by_number([7])
+    assert ag.ix.tolist() == [4, 1, 6] and len(ag) == 3 and len(set(ag)) == 3
+    assert U.select_atoms("bynum 5 2").ix.tolist() == [1, 4]       # one selection sorts, as MDAnalysis does
+    assert U.select_atoms("bynum 2:4").ix.tolist() == [1, 2, 3]
+    pdb = tmp_path / "m.pdb"
+    with open(pdb, "w") as fh:
+        for i, (x, y, z) in enumerate(wl.ALA_DIPEPTIDE_XYZ.tolist()):
+            fh.write("ATOM  %5d  C%-2d ALA  %4d    %8.3f%8.3f%8.3f\n" % (i + 1, i % 9, 1 + i // 8, x, y, z))
+    u2 = Universe.from_pdb(str(pdb))
+    assert np.array_equal(u2.atoms.positions, wl.ALA_DIPEPTIDE_XYZ)
+    assert len(u2.select_atoms("resid 2")) == 8
+
+
+def test_feature_file_reader(tmp_path):
+    """Same file format as the reference's feature files (feature.py:147-194)."""
+    f = tmp_path / "feat.txt"
+    f.write_text("# comment\n[Pre]\np1, position, bynum 7:16\n[End]\n[Hist]\n"
+                 "d1, dihedral, bynum 5, bynum 7, bynum 9, bynum 15\nb1, bond, bynum 2 5\n"
+                 "a1, angle, bynum 20, bynum 19, bynum 21\n[End]\n[Out]\nd2, dihedral, bynum 7 9 15 17\n[End]\n")
+    r = FeatureFileReader(str(f), "Hist", U)
+    feats = r.read()
+    assert [x.get_name() for x in feats] == ["d1", "b1", "a1"] and r.get_num_of_features() == 3
+    assert [x.get_type_id() for x in feats] == [2, 1, 0]
+    assert feats[0].get_atom_indices().tolist() == [5, 7, 9, 15]
+    assert feats[2].get_atom_indices().tolist() == [20, 19, 21]   # concatenation keeps the written order
+    assert list(r.get_feature_info()["name"]) == ["d1", "b1", "a1"]
+    pre = FeatureFileReader(str(f), "Pre", U).read()
+    assert pre[0].get_type() == "position" and len(pre[0].get_atom_indices()) == 10
+    fl = FeatureLayer(feats, U.atoms)
+    assert fl.output_dimension() == 4 and fl.get_feature(1).get_name() == "b1"
+    assert list(fl.get_feature_info()["type_id"]) == [2, 1, 0]
+
+
+def test_workload_sizes_match_baseline_table():
+    """algorithmic / dense bytes per frame."""
+    want = {"C1": (84, 276), "C2": (84, 276), "C3": (140, 296), "C4": (None, 60032), "C5": (None, 60064)}
+    for name, (alg, dense) in want.items():
+        w = wl.get_workload(name)
+        if alg is not None:
+            assert w.algorithmic_bytes_per_frame() == alg
+        assert w.dense_bytes_per_frame() == dense
+    assert wl.get_workload("C4").feature_dim() == 85 and wl.get_workload("C5").feature_dim() == 341
+    assert len(wl.get_workload("C4").align) == 312
+    assert wl.get_workload("C4").algorithmic_bytes_per_frame() <= 6068
