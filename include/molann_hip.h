@@ -156,6 +156,15 @@ const char* molann_error_string(int code);
  * Writes a NUL-terminated string of at most `cap` bytes; returns its length. */
 int molann_plan_last_launch_info(const molann_plan* plan, char* buf, int cap);
 
+/* Diagnostic / test hook: the source of the plan-specialised lane kernel for a description (copied to
+ * buf, NUL-terminated, at most cap bytes) and, if do_compile != 0, a hipRTC compile of it for gfx950 (no
+ * GPU needed).  Returns the source length; on a compile failure a positive hiprtcResult and the log in buf. */
+int molann_debug_jit(const molann_plan_desc* desc, int do_compile, char* buf, int cap);
+
+/* Diagnostic: per-phase shader-clock sums recorded when MOLANN_DEBUG_ABLATE has bit 32 set (see
+ * tools/stamps.py); reads and clears 8 counters.  Synchronises the device: never on a product path. */
+int molann_debug_read_stamps(unsigned long long* out8);
+
 /* Self-test hooks: the __host__ __device__ math the kernels are built from, compiled for the HOST, so
  * the CPU test-suite can check it against the oracle without a GPU.  Not a product path. */
 int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9);

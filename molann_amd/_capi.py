@@ -49,7 +49,7 @@ def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (seconds).  Used by __graft_entry__.build()."""
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(os.path.join(_CSRC, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("molann_kernels.hip", "molann_math.h")) or os.path.getmtime(HEADER_PATH) > os.path.getmtime(LIB_PATH):
+            for f in ("molann_kernels.hip", "molann_math.h", "molann_lane_jit.inc")) or os.path.getmtime(HEADER_PATH) > os.path.getmtime(LIB_PATH):
         subprocess.check_call(["make", "-C", _CSRC, "libmolann_hip.so"])
     return LIB_PATH
 
@@ -81,6 +81,8 @@ def lib():
             "molann_forward_f32": (i32, [vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
             "molann_mlp_packed_f32": (i32, [vp, vp, i64, vp, vp]),
             "molann_plan_last_launch_info": (i32, [vp, ctypes.c_char_p, i32]),
+            "molann_debug_read_stamps": (i32, [vp]),
+            "molann_debug_jit": (i32, [ctypes.POINTER(PlanDesc), i32, ctypes.c_char_p, i32]),
             "molann_selftest_kabsch_rotation": (i32, [vp, ctypes.c_double, vp]),
             "molann_selftest_feature": (i32, [i32, i32, vp, vp]),
             "molann_selftest_activation": (f32, [i32, f32]),

@@ -27,13 +27,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
 #include <algorithm>
 #include <new>
+#include <string>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/molann_hip.h"
 #include "molann_math.h"
+#include "jit_sources.gen.h"
 
 using namespace molann;
 
@@ -61,6 +66,7 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ItemDev { // one expanded feature item, 32 bytes
     int type;    // ItemType
@@ -84,6 +90,7 @@ struct PreArgs {
     int mode;         // 0: features (+ fused MLP)   1: aligned coordinates
     int n_align;
     int n_items;
+    int n_slots;      // touched atoms of the register-resident mode
     int out_cols;     // columns written per frame in mode 0
     int step_f;       // 64 / out_cols
     int step_c;       // 64 % out_cols
@@ -175,6 +182,19 @@ __device__ __forceinline__ void activate(int act, float (&h)[W]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// diagnostic phase stamps (MOLANN_DEBUG_ABLATE bit 32): per-phase shader-clock sums of every wave,
+// added to this array by lane 0 at kernel end and read back by molann_debug_read_stamps.  Shares of a
+// wave's time, not a timing of the production kernel (the stamps drain LDS/scalar queues).
+// ---------------------------------------------------------------------------------------------
+__device__ unsigned long long g_stamps[8];
+
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
 // lane-kernel helpers
 // ---------------------------------------------------------------------------------------------
 // Plan constants (align table, feature table) are held one record per LANE in VGPRs for the whole
@@ -227,8 +247,12 @@ __device__ __forceinline__ f32x4 mfma_chain(const float (&wa)[8], int w0, const 
 // =============================================================================================
 // frames_lane_kernel: one lane per frame, 64-frame tiles staged through LDS by LDS-DMA
 // =============================================================================================
-// ALIGN_OUT = true : AlignmentLayer.forward, aligned frames written back.
-// ALIGN_OUT = false: features (+ fused MLP when NL > 0).
+// MODE 1 (align-out): AlignmentLayer.forward, aligned frames written back.
+// MODE 0 (features) : features (+ fused MLP when NL > 0), atoms read from the LDS tile where needed.
+// MODE 2 (features, register-resident): at most 16 touched atoms ("slots", align atoms first).  As soon
+//   as the tile lands each lane copies its frame's touched atoms into 48 registers (static fill; later
+//   reads index the register file with a wave-uniform index, s_set_gpr_idx) and the tile buffer goes
+//   straight back to the DMA engine, so the next tile's HBM latency runs under ALL of this tile's work.
 // (Staging only the touched atoms with per-lane-address 12-byte LDS-DMA was measured and rejected: it
 // halves the LDS footprint but each such instruction touches 64 different 128-B lines, ~9 us per staged
 // atom per 1M frames against 66 us for the whole dense tile.)
@@ -245,14 +269,17 @@ __device__ __forceinline__ f32x4 mfma_chain(const float (&wa)[8], int w0, const 
 //   * The last layer's accumulator holds out[frame][16ub + 4q + r], r = 0..3: one 16-byte store per
 //     lane, whole output rows per 16-lane group.
 // fp32 MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so this is fp32 math.
-template <int NL, bool ALIGN_OUT>
+template <int NL, int MODE>
 __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           const int* __restrict__ align_tbl_g,
                                                           const float* __restrict__ ref_g,    // [a*3] + consts
                                                           const double* __restrict__ ref64_g, // same, fp64
                                                           const ItemDev* __restrict__ items_g,
+                                                          const int* __restrict__ slots_g, // MODE 2: slot -> atom
                                                           const float* __restrict__ wfrag_g, PreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool ALIGN_OUT = (MODE == 1);
+    constexpr bool REGS = (MODE == 2);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
@@ -261,6 +288,8 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
     float* fbuf = (float*)(wreg + a.fbuf_off);
     const auto ref = as_const(ref_g);
     const auto ref64 = as_const(ref64_g);
+    int slot_atom = 0; // MODE 2: lane u holds the atom index of slot u (0 beyond n_slots: a valid atom)
+    if (REGS && lane < a.n_slots) slot_atom = slots_g[lane];
 
     const long n_tiles = (a.n_frames + 63) >> 6;
     const long t_first = (long)blockIdx.x * wpb + wave;
@@ -305,35 +334,63 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
         ro_c0 = lane - ro_f0 * a.out_cols;
     }
 
+    const bool stamps = (a.ablate & 32) != 0;
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, ts = 0;
+#define MOLANN_STAMP(i)                            \
+    if (stamps) {                                  \
+        const unsigned long long now_ = stamp();   \
+        ph[i] += now_ - ts;                        \
+        ts = now_;                                 \
+    }
+    if (stamps) ts = stamp();
     for (long t = t_first; t < n_tiles; t += t_step) {
         const long rem = a.n_frames - t * 64;
         const int nfr = rem < 64 ? (int)rem : 64;
         // ---- 1. the tile was requested one iteration ago (or above): wait for the LDS-DMA -------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MOLANN_STAMP(0) // waiting for DMA + previous stores
 
         // lanes past the end of the batch recompute the last valid frame (their stores are masked)
         const int fl = lane < nfr ? lane : nfr - 1;
         const float* fr = tile + fl * a.frame_dw;
 
+        f32x16 ax, ay, az; // MODE 2: the touched atoms of this lane's frame
+        if constexpr (REGS) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const V3 p = lds_atom(fr, bcast(slot_atom, u));
+                ax[u] = p.x; ay[u] = p.y; az[u] = p.z;
+            }
+            // the tile is dead: hand its buffer back to the DMA engine for the next tile right now
+            if (t + t_step < n_tiles) stage_tile_dense(x, tile, t + t_step, a, lane);
+        }
+        MOLANN_STAMP(1) // register fill + DMA issue
+
         // ---- 2. Kabsch (ann.py:179-195) --------------------------------------------------------
         float R[9];
         V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
         if (has_align) {
-            c0 = lds_atom(fr, bcast(al_idx, 0)); // provisional centre: first align atom
             float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
             double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
             const int na = (a.ablate & 8) ? 1 : a.n_align;
-#pragma unroll 4
-            for (int i = 0; i < na; ++i) {
-                const int k = bcast(al_idx, i);
-                const double rx = bcast(al_rx, i), ry = bcast(al_ry, i), rz = bcast(al_rz, i);
-                const V3 p = lds_atom(fr, k) - c0;
+            auto accumulate = [&](const V3 p, const double rx, const double ry, const double rz) {
                 sx += p.x; sy += p.y; sz += p.z;
                 g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
                 const double px = p.x, py = p.y, pz = p.z;
                 h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
                 h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
                 h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            };
+            if constexpr (REGS) {
+                c0 = v3(ax[0], ay[0], az[0]); // provisional centre: first align atom = slot 0
+#pragma unroll
+                for (int i = 0; i < 16; ++i) // align atom i IS slot i (plan guarantees it)
+                    if (i < na) accumulate(v3(ax[i], ay[i], az[i]) - c0, bcast(al_rx, i), bcast(al_ry, i), bcast(al_rz, i));
+            } else {
+                c0 = lds_atom(fr, bcast(al_idx, 0)); // provisional centre: first align atom
+#pragma unroll 4
+                for (int i = 0; i < na; ++i)
+                    accumulate(lds_atom(fr, bcast(al_idx, i)) - c0, bcast(al_rx, i), bcast(al_ry, i), bcast(al_rz, i));
             }
             // constants after the reference coordinates: sum ref (3), sum |ref|^2, 1/a, a
             const int cb = 3 * a.n_align;
@@ -346,12 +403,14 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
             h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
             h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
             const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            MOLANN_STAMP(2) // covariance accumulation
             if (a.ablate & 1) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) R[i] = (float)h[i];
             } else {
                 kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
             }
+            MOLANN_STAMP(3) // rotation solve
         }
 
         if constexpr (ALIGN_OUT) {
@@ -392,8 +451,14 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                     i0 = items[8 * it + 2]; i1 = items[8 * it + 3]; i2 = items[8 * it + 4]; i3 = items[8 * it + 5];
                 }
                 // unused entries of an item repeat its first atom: always four reads in one batch
-                V3 p0 = lds_atom(fr, i0), p1 = lds_atom(fr, i1);
-                V3 p2 = lds_atom(fr, i2), p3 = lds_atom(fr, i3);
+                V3 p0, p1, p2, p3;
+                if constexpr (REGS) { // wave-uniform register index (s_set_gpr_idx)
+                    p0 = v3(ax[i0], ay[i0], az[i0]); p1 = v3(ax[i1], ay[i1], az[i1]);
+                    p2 = v3(ax[i2], ay[i2], az[i2]); p3 = v3(ax[i3], ay[i3], az[i3]);
+                } else {
+                    p0 = lds_atom(fr, i0); p1 = lds_atom(fr, i1);
+                    p2 = lds_atom(fr, i2); p3 = lds_atom(fr, i3);
+                }
                 if (has_align) { // features see the ALIGNED frame (ann.py:565)
                     p0 = rotate((p0 - c0) - dl, R);
                     if (type != IT_POSITION) {
@@ -409,9 +474,10 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                 if (w > 2) fbuf[(col + 2) * FB_STRIDE + lane] = v[2];
             }
 
-            // The atoms are dead from here on: start the next tile's LDS-DMA now, so that its HBM latency
-            // runs under the MLP and the stores of this tile.
-            if (t + t_step < n_tiles) stage_tile_dense(x, tile, t + t_step, a, lane);
+            // MODE 0: the tile is dead from here on: start the next tile's LDS-DMA now, so that its HBM
+            // latency runs under the MLP and the stores of this tile (MODE 2 did it right after the fill).
+            if (!REGS && t + t_step < n_tiles) stage_tile_dense(x, tile, t + t_step, a, lane);
+            MOLANN_STAMP(4) // feature table
 
             if constexpr (NL > 0) {
                 // ---- 4. fused MLP on the fp32 MFMA, four blocks of 16 frames ------------------
@@ -464,7 +530,7 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                     }
                     // D[ub][r] = out[frame 16 fb + i16][16 ub + 4 q + r]
                     const int frame = 16 * fb + i16;
-                    if (frame < nfr) {
+                    if (frame < nfr && !(a.ablate & 16)) {
                         float* orow = gout + (long)frame * a.out_cols;
 #pragma unroll
                         for (int ub = 0; ub < 2; ++ub) {
@@ -492,6 +558,12 @@ __global__ __launch_bounds__(256) void frames_lane_kernel(const float* __restric
                 }
             }
         }
+        MOLANN_STAMP(5) // MLP / read-out + stores
+    }
+#undef MOLANN_STAMP
+    if (stamps && lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], ph[i]);
+        atomicAdd(&g_stamps[7], 1ull);
     }
 }
 
@@ -818,6 +890,16 @@ struct molann_plan {
     int mlp_ld, mlp_lds_per_wave;
     // lane kernel geometry: [0] feature mode (tile + staging columns), [1] align-out mode (tile only)
     struct LaneGeom { int lds_per_wave, fbuf_off, wpb, ok; } geom[2];
+    // register-resident mode: <= 16 touched atoms ("slots", align atoms first) and tables in slot indices
+    // plan-specialised lane kernel (hipRTC), feature mode; nullptr -> generic kernel
+    hipModule_t jit_mod;
+    hipFunction_t jit_fn;
+    int jit_nl;          // Linear layers fused into it (0: features only)
+    char jit_note[96];
+    int n_slots;
+    bool regs_mode;
+    int* d_slots;
+    ItemDev* d_items_slot;
     bool mlp_packed;
     char last_info[256];
 };
@@ -908,6 +990,7 @@ void fill_pre_args(const molann_plan* p, PreArgs& a, long n_frames, int mode, in
     const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
     a.lds_per_wave = g.lds_per_wave;
     a.fbuf_off = g.fbuf_off;
+    a.n_slots = p->n_slots;
     a.x_wide = (((uintptr_t)x) & 15) == 0;
     a.out_wide = (((uintptr_t)out) & 15) == 0;
     a.n_layers = with_mlp ? p->n_layers : 0;
@@ -916,6 +999,119 @@ void fill_pre_args(const molann_plan* p, PreArgs& a, long n_frames, int mode, in
     a.out_vec4 = (a.out_wide && (a.out_cols & 3) == 0) ? 1 : 0;
     const char* dbg = getenv("MOLANN_DEBUG_ABLATE");
     a.ablate = dbg ? atoi(dbg) : 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// plan-time specialisation of the lane kernel (molann_lane_jit.inc) through hipRTC
+// ---------------------------------------------------------------------------------------------
+struct RtcApi {
+    decltype(&hiprtcCreateProgram) create;
+    decltype(&hiprtcCompileProgram) compile;
+    decltype(&hiprtcGetCodeSize) code_size;
+    decltype(&hiprtcGetCode) code;
+    decltype(&hiprtcGetProgramLogSize) log_size;
+    decltype(&hiprtcGetProgramLog) log;
+    decltype(&hiprtcDestroyProgram) destroy;
+    bool ok;
+};
+
+const RtcApi* rtc_api() {
+    static RtcApi api = [] {
+        RtcApi a;
+        memset(&a, 0, sizeof(a));
+        void* h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libhiprtc.so.7", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.create = (decltype(a.create))dlsym(h, "hiprtcCreateProgram");
+        a.compile = (decltype(a.compile))dlsym(h, "hiprtcCompileProgram");
+        a.code_size = (decltype(a.code_size))dlsym(h, "hiprtcGetCodeSize");
+        a.code = (decltype(a.code))dlsym(h, "hiprtcGetCode");
+        a.log_size = (decltype(a.log_size))dlsym(h, "hiprtcGetProgramLogSize");
+        a.log = (decltype(a.log))dlsym(h, "hiprtcGetProgramLog");
+        a.destroy = (decltype(a.destroy))dlsym(h, "hiprtcDestroyProgram");
+        a.ok = a.create && a.compile && a.code_size && a.code && a.log_size && a.log && a.destroy;
+        return a;
+    }();
+    return &api;
+}
+
+std::string join_chunks(const char* const* chunks) {
+    std::string s;
+    for (int i = 0; chunks[i]; ++i) s += chunks[i];
+    return s;
+}
+
+struct JitSpec { // what the specialised kernel is compiled for
+    int n_inp, n_align, n_layers, act, d_feat, out_cols, wpb, lds_per_wave, fbuf_off;
+    std::vector<int> slots;           // slot -> atom
+    std::vector<ItemDev> items;       // atoms as slot indices
+    std::vector<int> dims;
+};
+
+constexpr int JIT_MAX_ITEMS = 48, JIT_MAX_SLOTS = 32;
+
+std::string jit_source(const JitSpec& j) {
+    std::string s = "// preamble generated from the plan\n";
+    char b[256];
+    auto K = [&](const char* name, int v) { snprintf(b, sizeof(b), "constexpr int %s = %d;\n", name, v); s += b; };
+    K("N_INP", j.n_inp); K("N_ALIGN", j.n_align); K("N_SLOTS", (int)j.slots.size()); K("N_ITEMS", (int)j.items.size());
+    K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
+    K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
+    const char* dbg = getenv("MOLANN_DEBUG_ABLATE");
+    s += (dbg && (atoi(dbg) & 32)) ? "constexpr bool STAMPS = true;\n" : "constexpr bool STAMPS = false;\n";
+    auto A = [&](const char* name, const std::vector<int>& v) {
+        s += std::string("constexpr int ") + name + "[] = {";
+        for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
+        s += "};\n";
+    };
+    std::vector<int> used(j.slots.size(), 0), type, col;
+    A("SLOT_ATOM", j.slots);
+    s += "constexpr int ITEM_IDX[][4] = {";
+    for (size_t i = 0; i < j.items.size(); ++i) {
+        const ItemDev& it = j.items[i];
+        const int na = item_atoms(it.type);
+        for (int k = 0; k < na; ++k) used[it.idx[k]] = 1;
+        type.push_back(it.type);
+        col.push_back(it.col);
+        snprintf(b, sizeof(b), "%s{%d, %d, %d, %d}", i ? ", " : "", it.idx[0], it.idx[1], it.idx[2], it.idx[3]);
+        s += b;
+    }
+    s += "};\n";
+    A("ITEM_TYPE", type); A("ITEM_COL", col); A("SLOT_USED", used);
+    std::vector<int> dims = j.dims;
+    if (dims.empty()) dims.push_back(j.d_feat);
+    while (dims.size() < 2) dims.push_back(1); // the kernel text names DIMS[1] even when NL == 0 discards its use
+    A("DIMS", dims);
+    s += "#line 1 \"molann_lane_jit.inc\"\n";
+    s += join_chunks(k_src_molann_lane_jit_inc);
+    return s;
+}
+
+// compile to a gfx950 code object; returns 0 or a hiprtcResult, log filled on failure
+int jit_compile(const std::string& src, std::vector<char>& code, std::string& log) {
+    const RtcApi* rtc = rtc_api();
+    if (!rtc->ok) { log = "libhiprtc.so not found"; return -1; }
+    const std::string math = join_chunks(k_src_molann_math_h);
+    const char* hdr_src[] = {math.c_str()};
+    const char* hdr_name[] = {"molann_math.h"};
+    hiprtcProgram prog;
+    hiprtcResult r = rtc->create(&prog, src.c_str(), "molann_lane_jit.hip", 1, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return (int)r; }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    r = rtc->compile(prog, 3, opts);
+    size_t ls = 0;
+    rtc->log_size(prog, &ls);
+    if (ls > 1) { log.resize(ls); rtc->log(prog, &log[0]); }
+    if (r == HIPRTC_SUCCESS) {
+        size_t cs = 0;
+        rtc->code_size(prog, &cs);
+        code.resize(cs);
+        rtc->code(prog, code.data());
+    }
+    rtc->destroy(&prog);
+    return (int)r;
 }
 
 // preprocessing (align / features / fused forward) for n_frames starting at x -> out
@@ -932,21 +1128,39 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         if (bpc < 1) bpc = 1;
         if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
         const int grid = grid_for(p, n_tiles, wpb, bpc);
-        const size_t lds = (size_t)wpb * g.lds_per_wave;
+        size_t lds = (size_t)wpb * g.lds_per_wave;
+        if (const char* pad = getenv("MOLANN_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad); // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
-#define LAUNCH_LANE(W, AO)                                                                                      \
-    hipLaunchKernelGGL((frames_lane_kernel<W, AO>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
-                       p->d_ref64, p->d_items, p->d_wlane, a)
-        if (mode == 1) LAUNCH_LANE(0, true);
-        else if (w == 0) LAUNCH_LANE(0, false);
-        else if (w == 1) LAUNCH_LANE(1, false);
-        else if (w == 2) LAUNCH_LANE(2, false);
-        else if (w == 3) LAUNCH_LANE(3, false);
-        else LAUNCH_LANE(4, false);
+        if (mode == 0 && p->jit_fn && (a.ablate & ~32) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+            unsigned long long* stamps = nullptr;
+            if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
+            struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
+                     unsigned long long* stamps; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide, a.out_vec4, stamps};
+            size_t ksz = sizeof(ka);
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+            const hipError_t le = hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, 64 * wpb, 1, 1, (unsigned)lds, stream, nullptr, cfg);
+            snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised) grid=%d block=%d lds=%zu",
+                     p->jit_nl, grid, 64 * wpb, lds);
+            return (int)le;
+        }
+        const bool regs = p->regs_mode && !getenv("MOLANN_DEBUG_NO_REGS");
+#define LAUNCH_LANE(W, M)                                                                                         \
+    hipLaunchKernelGGL((frames_lane_kernel<W, M>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
+                       p->d_ref64, (M == 2 ? p->d_items_slot : p->d_items), p->d_slots, p->d_wlane, a)
+#define LAUNCH_LANE_W(M)            \
+    if (w == 0) LAUNCH_LANE(0, M);  \
+    else if (w == 1) LAUNCH_LANE(1, M); \
+    else if (w == 2) LAUNCH_LANE(2, M); \
+    else if (w == 3) LAUNCH_LANE(3, M); \
+    else LAUNCH_LANE(4, M)
+        if (mode == 1) LAUNCH_LANE(0, 1);
+        else if (regs) { LAUNCH_LANE_W(2); }
+        else { LAUNCH_LANE_W(0); }
+#undef LAUNCH_LANE_W
 #undef LAUNCH_LANE
         snprintf(p->last_info, sizeof(p->last_info), "frames_lane_kernel<%d,%s> grid=%d block=%d lds=%zu", w,
-                 mode == 1 ? "align_out" : "features", grid, 64 * wpb, lds);
+                 mode == 1 ? "align_out" : (regs ? "features_regs" : "features_lds"), grid, 64 * wpb, lds);
     } else {
         const int wpb = 4;
         const int grid = grid_for(p, n_frames, wpb, 8);
@@ -1074,6 +1288,19 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const bool small_mlp = d->n_layers > 0 && d->n_layers <= LANE_MLP_MAX_LAYERS && max_w <= LANE_MLP_MAX_WIDTH &&
                            d_feat <= LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
     const int cols_needed = std::max(1, small_mlp ? ceil_to(d_feat, 4) : d_feat);
+    // touched atoms -> slots in first-use order: align atoms, then the feature table's atoms
+    std::vector<int> slot_of(d->n_inp, -1), slots;
+    auto slot = [&](int atom) {
+        if (slot_of[atom] < 0) { slot_of[atom] = (int)slots.size(); slots.push_back(atom); }
+        return slot_of[atom];
+    };
+    bool align_is_prefix = true; // align atom i must be slot i (no repeated align atoms)
+    for (int i = 0; i < d->n_align; ++i) align_is_prefix = align_is_prefix && (slot(d->align_idx[i]) == i);
+    std::vector<ItemDev> items_slot(items);
+    for (auto& it : items_slot)
+        for (int i = 0; i < 4; ++i) it.idx[i] = slot(it.idx[i]);
+    p->n_slots = (int)slots.size();
+    p->regs_mode = p->n_items > 0 && p->n_items <= 64 && p->n_slots <= 16 && align_is_prefix;
     memset(p->geom, 0, sizeof(p->geom));
     const bool lane_tables_fit = d->n_align <= 64 && (long)d->n_inp * 768 <= 65536;
     if (p->n_items > 0 && lane_tables_fit && cols_needed <= LANE_MAX_COLS)
@@ -1090,6 +1317,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const size_t o_ref = carve(sizeof(float) * (3 * (size_t)d->n_align + 8));
     const size_t o_ref64 = carve(sizeof(double) * (3 * (size_t)d->n_align + 8));
     const size_t o_items = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
+    const size_t o_items_slot = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
+    const size_t o_slots = carve(sizeof(int) * std::max<size_t>(1, slots.size()));
 
     size_t lane_floats = 0;
     if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512);
@@ -1143,6 +1372,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_ref = (float*)(p->blob + o_ref);
     p->d_ref64 = (double*)(p->blob + o_ref64);
     p->d_items = (ItemDev*)(p->blob + o_items);
+    p->d_items_slot = (ItemDev*)(p->blob + o_items_slot);
+    p->d_slots = (int*)(p->blob + o_slots);
     p->d_wlane = (float*)(p->blob + o_wlane);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
@@ -1174,15 +1405,45 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     }
     if (e == hipSuccess && !items.empty())
         e = hipMemcpy(p->d_items, items.data(), sizeof(ItemDev) * items.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !items.empty())
+        e = hipMemcpy(p->d_items_slot, items_slot.data(), sizeof(ItemDev) * items.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !slots.empty())
+        e = hipMemcpy(p->d_slots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice);
 
     if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
+    // ---- plan-specialised lane kernel --------------------------------------------------------------
+    snprintf(p->jit_note, sizeof(p->jit_note), "jit: not applicable");
+    const char* nojit = getenv("MOLANN_NO_JIT");
+    if (p->geom[0].ok && align_is_prefix && p->n_items <= JIT_MAX_ITEMS && p->n_slots <= JIT_MAX_SLOTS &&
+        !(nojit && nojit[0] == '1')) {
+        JitSpec j;
+        j.n_inp = d->n_inp; j.n_align = d->n_align; j.act = d->activation; j.d_feat = d_feat;
+        j.n_layers = p->fused_mlp ? d->n_layers : 0;
+        j.out_cols = p->fused_mlp ? p->out_dim : d_feat;
+        j.wpb = p->geom[0].wpb; j.lds_per_wave = p->geom[0].lds_per_wave; j.fbuf_off = p->geom[0].fbuf_off;
+        j.slots = slots; j.items = items_slot;
+        if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
+        std::vector<char> code;
+        std::string log;
+        const int rc = jit_compile(jit_source(j), code, log);
+        if (rc == 0 && hipModuleLoadData(&p->jit_mod, code.data()) == hipSuccess &&
+            hipModuleGetFunction(&p->jit_fn, p->jit_mod, "molann_lane_jit") == hipSuccess) {
+            p->jit_nl = j.n_layers;
+            snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %zu bytes", code.size());
+        } else {
+            p->jit_fn = nullptr;
+            snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
+            if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
+        }
+    }
     *out_plan = p;
     return MOLANN_OK;
 }
 
 int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
+    if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
     hipError_t e = hipFree(p->blob);
     delete p;
     return (int)e;
@@ -1293,6 +1554,68 @@ int molann_forward_f32(molann_plan* p, const float* x, int64_t n, const float* c
     const int e = molann_plan_update_mlp(p, W, b, stream);
     if (e != MOLANN_OK) return e;
     return molann_forward_packed_f32(p, x, n, out, stream);
+}
+
+// diagnostic / test hook: generate (and optionally compile, needs no GPU) the plan-specialised kernel
+// source for a description.  Returns the source length, or a negative MOLANN_E_* / positive hiprtcResult.
+int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int cap) {
+    const int v = validate_desc(d);
+    if (v != MOLANN_OK) return v;
+    JitSpec j;
+    std::vector<int> slot_of(d->n_inp, -1);
+    auto slot = [&](int atom) {
+        if (slot_of[atom] < 0) { slot_of[atom] = (int)j.slots.size(); j.slots.push_back(atom); }
+        return slot_of[atom];
+    };
+    for (int i = 0; i < d->n_align; ++i)
+        if (slot(d->align_idx[i]) != i) return MOLANN_E_UNSUPPORTED;
+    int col = 0;
+    for (int f = 0; f < d->n_features; ++f) {
+        const int* idx = d->feat_idx + d->feat_ptr[f];
+        const int cnt = d->feat_ptr[f + 1] - d->feat_ptr[f], t = d->feat_type[f];
+        if (t == MOLANN_FEAT_POSITION) {
+            for (int i = 0; i < cnt; ++i) { ItemDev it = {IT_POSITION, col, {slot(idx[i]), 0, 0, 0}, {0, 0}}; it.idx[1] = it.idx[2] = it.idx[3] = it.idx[0]; j.items.push_back(it); col += 3; }
+        } else {
+            ItemDev it;
+            it.type = t == MOLANN_FEAT_ANGLE ? (d->use_angle_value ? IT_ANGLE_VAL : IT_ANGLE_COS)
+                      : t == MOLANN_FEAT_BOND ? IT_BOND : (d->use_angle_value ? IT_DIHEDRAL_VAL : IT_DIHEDRAL_CS);
+            it.col = col;
+            for (int i = 0; i < 4; ++i) it.idx[i] = slot(idx[i < cnt ? i : 0]);
+            it.pad[0] = it.pad[1] = 0;
+            j.items.push_back(it);
+            col += item_width(it.type);
+        }
+    }
+    if (j.items.empty() || (int)j.items.size() > JIT_MAX_ITEMS || (int)j.slots.size() > JIT_MAX_SLOTS) return MOLANN_E_UNSUPPORTED;
+    j.n_inp = d->n_inp; j.n_align = d->n_align; j.act = d->activation; j.d_feat = col;
+    j.n_layers = d->n_layers; j.out_cols = d->n_layers > 0 ? d->layer_dims[d->n_layers] : col;
+    if (d->n_layers > 0) j.dims.assign(d->layer_dims, d->layer_dims + d->n_layers + 1);
+    molann_plan::LaneGeom g;
+    lane_geometry(g, 64 * d->n_inp * 12, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
+    if (!g.ok) return MOLANN_E_UNSUPPORTED;
+    j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
+    const std::string src = jit_source(j);
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", src.c_str());
+    if (do_compile) {
+        std::vector<char> code;
+        std::string log;
+        const int rc = jit_compile(src, code, log);
+        if (rc != 0) {
+            if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", log.c_str());
+            return rc > 0 ? rc : MOLANN_E_UNSUPPORTED;
+        }
+    }
+    return (int)src.size();
+}
+
+// diagnostic: read and clear the phase-stamp sums (8 x u64; [7] = number of waves that reported)
+int molann_debug_read_stamps(unsigned long long* out8) {
+    if (!out8) return MOLANN_E_NULL;
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
+    return MOLANN_OK;
 }
 
 // ---- self-test hooks: the same __host__ __device__ source, compiled for the host -------------

@@ -7,8 +7,10 @@
 //   activations   molann/ann.py:37,64     (the module placed between the Linear layers)
 #pragma once
 
+#if !defined(__HIPCC_RTC__) // hipRTC provides the runtime declarations and libm itself
 #include <hip/hip_runtime.h>
 #include <math.h>
+#endif
 
 #define MOLANN_HD __host__ __device__ __forceinline__
 
@@ -51,8 +53,8 @@ MOLANN_HD float fast_rsq(float x) {
     return 1.0f / sqrtf(x);
 #endif
 }
-// sqrt(x) for x >= 0 as x * rsq(x) (1-2 ulp), exact 0 at 0 like sqrtf
-MOLANN_HD float fast_sqrt(float x) { return x > 0.0f ? x * fast_rsq(x) : (x == 0.0f ? 0.0f : sqrtf(x)); }
+// sqrt(x) as x * rsq(x) (1-2 ulp): exact 0 at 0 like sqrtf, NaN for negative / NaN input
+MOLANN_HD float fast_sqrt(float x) { return x == 0.0f ? 0.0f : x * fast_rsq(x); }
 MOLANN_HD float fast_exp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __expf(x);

@@ -236,7 +236,7 @@ def test_capi_direct_forward_f32(hip_device):
     torch.cuda.synchronize()
     want = oracle_for_workload(w, model, x.cpu(), torch.float64)
     assert float((out.cpu().double() - want).abs().max()) <= 1e-5
-    assert "frames_lane_kernel" in plan.last_launch_info()
+    assert "lane" in plan.last_launch_info()      # generic or plan-specialised lane kernel
     # stage errors
     assert _capi.lib().molann_align_f32(plan._handle, ctypes.c_void_p(x.data_ptr()), 777,
                                         ctypes.c_void_p(out.data_ptr()), plan._stream()) == _capi.E_STAGE

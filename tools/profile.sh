@@ -3,11 +3,11 @@
 #   tools/profile.sh <workload> <tag>     -> gpurun_out/prof_<tag>/{stats,pmc_*}.csv summaries
 # PMC passes are separate runs with nothing but --pmc (gpurun refuses --pmc mixed with trace domains).
 set -u
-WL=${1:-C3}; TAG=${2:-$WL}
+WL=${1:-C3}; TAG=${2:-$WL}; EXTRA=${3:-}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline"
+ARGS="bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 find "$OUT/trace" -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > "$2"' _ {} "$OUT/kernel_trace_head.csv" \;
