@@ -101,7 +101,9 @@ def cpu_baseline(w, model, seconds):
         with torch.no_grad():
             for s in range(0, n, chunk):
                 xs = x[s:s + chunk]
-                if w.mlp_dims:
+                if w.kind == "align":
+                    mo.align_forward(xs, al, ref_x)
+                elif w.mlp_dims:
                     mo.molann_forward(xs, feats, ws, bs, w.use_angle_value, al, ref_x)
                 else:
                     mo.preprocessing_forward(xs, feats, w.use_angle_value, al, ref_x)
@@ -209,7 +211,7 @@ def main():
         plan_info = ""
         try:
             cache = model._plans()
-            plan_info = next(iter(cache.values())).plan.last_launch_info() if cache else ""
+            plan_info = list(cache.values())[-1].plan.last_launch_info() if cache else ""
         except Exception:
             pass
         rec = {

@@ -15,7 +15,9 @@
  *     by the caller; pointers inside molann_plan_desc are HOST pointers, read during plan_create only.
  *   - launch functions only enqueue work on `stream`: no host synchronisation, no allocation
  *     (graph-capturable).  They are thread-safe for distinct plans; one plan may be used from several
- *     streams as long as molann_plan_update_* calls are ordered before the launches that need them.
+ *     streams as long as molann_plan_update_* calls are ordered before the launches that need them -
+ *     except a plan whose MLP is not fused into the frame kernel (wide MLPs / large frames): it owns a
+ *     feature workspace, a side stream and events, so its forward calls must not overlap each other.
  *   - x is [n_frames, n_inp, 3] fp32, contiguous, frame-major / atom-major / xyz-minor (the layout of
  *     the tensor the reference's forward receives, ann.py:170).  Any 4-byte aligned pointer works;
  *     16-byte aligned pointers take the wide-load path.

@@ -670,7 +670,7 @@ struct MlpArgs {
     int kp[MOLANN_MAX_LAYERS];    // padded K per layer
     int jp[MOLANN_MAX_LAYERS];    // padded J per layer
     long woff[MOLANN_MAX_LAYERS]; // element offset of layer l in the packed buffer
-    int ld;                       // LDS row stride (elements) of both activation buffers
+    int ld[2];                    // LDS row strides (elements): buffer 0 feeds even layers, buffer 1 odd layers
     int lds_per_wave;             // bytes
     int in_stride;                // row stride of the input features (floats)
 };
@@ -680,19 +680,77 @@ __device__ __forceinline__ unsigned short f2bf(float f) { // round-to-nearest-ev
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// NBW n-blocks (16 output columns each) advance together: one A fragment read from LDS feeds NBW MFMAs on
+// NBW independent accumulator chains, their B fragments (weight rows, 16 B per lane) stream from L2.
+template <bool BF16, int NBW, typename elem_t>
+__device__ __forceinline__ void mlp_nblocks(const elem_t* __restrict__ W, const float* __restrict__ bias, const elem_t* cur,
+                                            int ld_cur, elem_t* nxt, int ld_nxt, float* __restrict__ out, long frame0,
+                                            int nrow, int n0, int Kp, int J, bool last, int act, int r16, int q) {
+    constexpr int KG = BF16 ? 32 : 16; // k's consumed per group (bf16: one MFMA; f32: four MFMAs)
+    constexpr int KQ = BF16 ? 8 : 4;   // contiguous k's per lane quad
+    f32x4 acc[NBW];
+    const elem_t* wrow[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const float bj = bias[n0 + 16 * b + r16]; // C[row 4q+reg][col r16]: bias depends on the column only
+        acc[b] = (f32x4){bj, bj, bj, bj};
+        wrow[b] = W + (long)(n0 + 16 * b + r16) * Kp + q * KQ;
+    }
+    const elem_t* arow = cur + r16 * ld_cur + q * KQ;
+#pragma unroll 2
+    for (int kg = 0; kg < Kp; kg += KG) {
+        if constexpr (BF16) {
+            const bf16x8 av = *(const bf16x8*)(arow + kg);
+            bf16x8 bv[NBW];
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) bv[b] = *(const bf16x8*)(wrow[b] + kg);
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[b], acc[b], 0, 0, 0);
+        } else {
+            const f32x4 av = *(const f32x4*)(arow + kg);
+            f32x4 bv[NBW];
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) bv[b] = *(const f32x4*)(wrow[b] + kg);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[b][s], acc[b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int col = n0 + 16 * b + r16;
+        if (last) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q + r;
+                if (row < nrow && col < J) out[(frame0 + row) * (long)J + col] = acc[b][r];
+            }
+        } else {
+            float h[4] = {acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
+            activate<4, false>(act, h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = col < J ? h[r] : 0.f; // padded columns feed zero into the next layer
+                if constexpr (BF16) nxt[(4 * q + r) * ld_nxt + col] = f2bf(v);
+                else nxt[(4 * q + r) * ld_nxt + col] = v;
+            }
+        }
+    }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void mlp_mfma_kernel(const float* __restrict__ feat, float* __restrict__ out,
                                                        const void* __restrict__ wpack_v, MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
-    constexpr int KG = BF16 ? 32 : 16; // k's consumed per group (bf16: one MFMA; f32: four MFMAs)
-    constexpr int KQ = BF16 ? 8 : 4;   // contiguous k's per lane quad
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    elem_t* bufA = (elem_t*)(smem + (size_t)wave * a.lds_per_wave);
-    elem_t* bufB = bufA + 16 * a.ld;
+    elem_t* buf[2];
+    buf[0] = (elem_t*)(smem + (size_t)wave * a.lds_per_wave);
+    buf[1] = buf[0] + 16 * a.ld[0];
     const elem_t* wpack = (const elem_t*)wpack_v;
     const long n_blocks = (a.n_frames + 15) >> 4;
 
@@ -703,66 +761,34 @@ __global__ __launch_bounds__(256) void mlp_mfma_kernel(const float* __restrict__
         // ---- stage the 16 input rows into LDS (zero padded to kp[0]) -------------------------
         {
             const int K0 = a.dims[0], Kp0 = a.kp[0];
+#pragma unroll 4
             for (int r = 0; r < 16; ++r) {
                 const float* src = feat + (frame0 + (r < nrow ? r : nrow - 1)) * (long)a.in_stride;
                 for (int k = lane; k < Kp0; k += 64) {
                     const float v = k < K0 ? src[k] : 0.f;
-                    if constexpr (BF16) bufA[r * a.ld + k] = f2bf(v);
-                    else bufA[r * a.ld + k] = v;
+                    if constexpr (BF16) buf[0][r * a.ld[0] + k] = f2bf(v);
+                    else buf[0][r * a.ld[0] + k] = v;
                 }
             }
         }
-        elem_t* cur = bufA;
-        elem_t* nxt = bufB;
         for (int l = 0; l < a.n_layers; ++l) {
             const int Kp = a.kp[l], Jp = a.jp[l], J = a.dims[l + 1];
             const elem_t* W = wpack + a.woff[l];
             const float* bias = (const float*)(W + (long)Jp * Kp);
             const bool last = (l + 1 == a.n_layers);
-            for (int n0 = 0; n0 < Jp; n0 += 16) {
-                const float bj = bias[n0 + r16];
-                f32x4 acc = {bj, bj, bj, bj}; // C[row 4q+reg][col r16]: bias depends on the column only
-                const elem_t* wrow = W + (long)(n0 + r16) * Kp + q * KQ;
-                const elem_t* arow = cur + r16 * a.ld + q * KQ;
-#pragma unroll 2
-                for (int kg = 0; kg < Kp; kg += KG) {
-                    if constexpr (BF16) {
-                        const bf16x8 bv = *(const bf16x8*)(wrow + kg);
-                        const bf16x8 av = *(const bf16x8*)(arow + kg);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
-                    } else {
-                        const f32x4 bv = *(const f32x4*)(wrow + kg);
-                        const f32x4 av = *(const f32x4*)(arow + kg);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc, 0, 0, 0);
-                    }
-                }
-                const int col = n0 + r16;
-                if (last) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q + r;
-                        if (row < nrow && col < J) out[(frame0 + row) * (long)J + col] = acc[r];
-                    }
-                } else {
-                    float h[4] = {acc[0], acc[1], acc[2], acc[3]};
-                    activate<4, false>(a.act, h);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = col < J ? h[r] : 0.f; // padded columns feed zero into the next layer
-                        if constexpr (BF16) nxt[(4 * q + r) * a.ld + col] = f2bf(v);
-                        else nxt[(4 * q + r) * a.ld + col] = v;
-                    }
-                }
-            }
+            const elem_t* cur = buf[l & 1];
+            elem_t* nxt = buf[(l + 1) & 1];
+            const int ld_cur = a.ld[l & 1], ld_nxt = a.ld[(l + 1) & 1];
+            int n0 = 0;
+            for (; n0 + 64 <= Jp; n0 += 64)
+                mlp_nblocks<BF16, 4>(W, bias, cur, ld_cur, nxt, ld_nxt, out, frame0, nrow, n0, Kp, J, last, a.act, r16, q);
+            for (; n0 < Jp; n0 += 16)
+                mlp_nblocks<BF16, 1>(W, bias, cur, ld_cur, nxt, ld_nxt, out, frame0, nrow, n0, Kp, J, last, a.act, r16, q);
             if (!last) { // zero the k padding of the next layer beyond Jp (kp[l+1] may exceed Jp)
                 const int Kn = a.kp[l + 1];
                 for (int k = Jp + lane; k < Kn; k += 64)
-                    for (int r = 0; r < 16; ++r) nxt[r * a.ld + k] = (elem_t)0;
+                    for (int r = 0; r < 16; ++r) nxt[r * ld_nxt + k] = (elem_t)0;
             }
-            elem_t* tmp = cur; cur = nxt; nxt = tmp;
         }
     }
 }
@@ -883,11 +909,13 @@ struct molann_plan {
     ItemDev* d_items;
     float* d_wlane;    // fused layout
     void* d_wmfma;     // mfma layout
-    float* d_work;     // feature chunk [work_frames][d_feat]
+    float* d_work;     // two feature chunks [2][work_frames][d_feat] (ping-pong between gather and MLP kernels)
     long work_frames;
+    hipStream_t side;  // the MLP kernel of chunk i runs here while the caller's stream gathers chunk i+1
+    hipEvent_t ev_feat[2], ev_mlp[2];
     int kp[MOLANN_MAX_LAYERS], jp[MOLANN_MAX_LAYERS];
     long moff[MOLANN_MAX_LAYERS];
-    int mlp_ld, mlp_lds_per_wave;
+    int mlp_ld[2], mlp_lds_per_wave;
     // lane kernel geometry: [0] feature mode (tile + staging columns), [1] align-out mode (tile only)
     struct LaneGeom { int lds_per_wave, fbuf_off, wpb, ok; } geom[2];
     // register-resident mode: <= 16 touched atoms ("slots", align atoms first) and tables in slot indices
@@ -1099,8 +1127,21 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
     hiprtcProgram prog;
     hiprtcResult r = rtc->create(&prog, src.c_str(), "molann_lane_jit.hip", 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return (int)r; }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    r = rtc->compile(prog, 3, opts);
+    std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    if (const char* extra = getenv("MOLANN_JIT_EXTRA_FLAGS")) { // experiments: space-separated compiler flags
+        std::string e(extra);
+        size_t pos = 0;
+        while (pos < e.size()) {
+            const size_t sp = e.find(' ', pos);
+            const std::string tok = e.substr(pos, sp == std::string::npos ? std::string::npos : sp - pos);
+            if (!tok.empty()) flags.push_back(tok);
+            if (sp == std::string::npos) break;
+            pos = sp + 1;
+        }
+    }
+    std::vector<const char*> opts;
+    for (auto& f : flags) opts.push_back(f.c_str());
+    r = rtc->compile(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     rtc->log_size(prog, &ls);
     if (ls > 1) { log.resize(ls); rtc->log(prog, &log[0]); }
@@ -1163,7 +1204,11 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
                  mode == 1 ? "align_out" : (regs ? "features_regs" : "features_lds"), grid, 64 * wpb, lds);
     } else {
         const int wpb = 4;
-        const int grid = grid_for(p, n_frames, wpb, 8);
+        // blocks per CU: all wave slots normally; on the unfused path leave registers and wave slots for the
+        // MLP kernel that runs beside this one on the plan's side stream (MOLANN_WAVE_BPC to experiment)
+        int bpc = (p->work_frames > 0 && mode == 0) ? 2 : 8;
+        if (const char* ev = getenv("MOLANN_WAVE_BPC")) bpc = std::max(1, atoi(ev));
+        const int grid = grid_for(p, n_frames, wpb, bpc);
         hipLaunchKernelGGL(frames_wave_kernel, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref,
                            p->d_ref64, p->d_items, a);
         snprintf(p->last_info, sizeof(p->last_info), "frames_wave_kernel grid=%d block=%d mode=%d", grid, 64 * wpb, mode);
@@ -1179,12 +1224,18 @@ int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, 
     a.act = p->act;
     for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
     for (int i = 0; i < p->n_layers; ++i) { a.kp[i] = p->kp[i]; a.jp[i] = p->jp[i]; a.woff[i] = p->moff[i]; }
-    a.ld = p->mlp_ld;
+    a.ld[0] = p->mlp_ld[0];
+    a.ld[1] = p->mlp_ld[1];
     a.lds_per_wave = p->mlp_lds_per_wave;
     a.in_stride = in_stride;
-    int wpb = 65536 / p->mlp_lds_per_wave;
-    if (wpb > 4) wpb = 4;
-    if (wpb < 1) wpb = 1; // one wave with up to 160 KiB (attribute raised at plan creation)
+    // block size that packs most waves into the CU's LDS (waves are independent), larger block on ties
+    int wpb = 1, best_waves = 0;
+    for (int w = 4; w >= 1; --w) {
+        if ((long)w * p->mlp_lds_per_wave > 65536 && w > 1) continue;
+        long waves = w * (163840 / ((long)w * p->mlp_lds_per_wave));
+        if (waves > 16) waves = 16;
+        if (waves > best_waves) { best_waves = (int)waves; wpb = w; }
+    }
     int bpc = (int)(163840 / ((long)wpb * p->mlp_lds_per_wave));
     if (bpc < 1) bpc = 1;
     if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
@@ -1341,8 +1392,16 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             mfma_bytes += ((size_t)p->jp[l] * p->kp[l]) * es + (size_t)p->jp[l] * 4;
             mfma_bytes = (mfma_bytes + 15) & ~(size_t)15;
         }
-        p->mlp_ld = max_kp + (bf16 ? 8 : 4); // row stride: 16-byte multiple, off the power of two
-        p->mlp_lds_per_wave = 2 * 16 * p->mlp_ld * (int)es;
+        // two activation buffers: [0] holds the inputs of even layers, [1] of odd layers (layer l writes what
+        // layer l+1 reads).  Row strides: 16-byte multiples, off the power of two.
+        int need[2] = {16, 16};
+        for (int l = 0; l < d->n_layers; ++l) {
+            need[l & 1] = std::max(need[l & 1], p->kp[l]);
+            if (l + 1 < d->n_layers) need[(l + 1) & 1] = std::max(need[(l + 1) & 1], std::max(p->jp[l], p->kp[l + 1]));
+        }
+        (void)max_kp;
+        for (int i = 0; i < 2; ++i) p->mlp_ld[i] = need[i] + (bf16 ? 8 : 4);
+        p->mlp_lds_per_wave = 16 * (p->mlp_ld[0] + p->mlp_ld[1]) * (int)es;
         if (p->mlp_lds_per_wave > 163840) { delete p; return MOLANN_E_UNSUPPORTED; }
         if (p->mlp_lds_per_wave > 65536) { // a single wave's two activation buffers exceed the default 64 KiB cap
             hipError_t ea = bf16 ? hipFuncSetAttribute((const void*)mlp_mfma_kernel<true>,
@@ -1361,8 +1420,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         long wf = (64l << 20) / ((long)d_feat * 4);
         wf = std::max<long>(1024, std::min<long>(wf, 1l << 18));
         wf &= ~63l;
+        wf = std::max<long>(512, (wf / 2) & ~63l); // per half
         p->work_frames = wf;
-        work_bytes = (size_t)wf * d_feat * 4;
+        work_bytes = 2 * (size_t)wf * d_feat * 4;
     }
     const size_t o_work = carve(std::max<size_t>(16, work_bytes));
 
@@ -1412,6 +1472,14 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
 
     if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
+    if (p->work_frames > 0) {
+        e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        for (int h = 0; h < 2 && e == hipSuccess; ++h) {
+            e = hipEventCreateWithFlags(&p->ev_feat[h], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_mlp[h], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
+    }
     // ---- plan-specialised lane kernel --------------------------------------------------------------
     snprintf(p->jit_note, sizeof(p->jit_note), "jit: not applicable");
     const char* nojit = getenv("MOLANN_NO_JIT");
@@ -1444,6 +1512,11 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
 int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        for (int h = 0; h < 2; ++h) { (void)hipEventDestroy(p->ev_feat[h]); (void)hipEventDestroy(p->ev_mlp[h]); }
+        (void)hipStreamDestroy(p->side);
+    }
     hipError_t e = hipFree(p->blob);
     delete p;
     return (int)e;
@@ -1533,18 +1606,29 @@ int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, 
     const int c = check_io(x, out, n);
     if (c != MOLANN_OK || n == 0) return c;
     if (p->fused_mlp) return launch_pre(p, x, n, out, 0, true, (hipStream_t)stream);
-    // unfused: features of a chunk -> plan workspace (cache resident) -> MFMA MLP
+    // unfused: features of a chunk -> plan workspace (cache resident) -> MFMA MLP.  Two workspace halves:
+    // the MLP of chunk i runs on the plan's side stream while this stream already gathers chunk i+1
+    // (HBM-bound gather next to an MFMA/L2-bound kernel); events fork and join, so capture still works.
     char info[256];
     info[0] = 0;
-    for (int64_t s = 0; s < n; s += p->work_frames) {
+    hipStream_t main = (hipStream_t)stream;
+    int i = 0;
+    for (int64_t s = 0; s < n; s += p->work_frames, ++i) {
+        const int h = i & 1;
         const long m = (long)std::min<int64_t>(p->work_frames, n - s);
-        int e = launch_pre(p, x + s * (long)p->n_inp * 3, m, p->d_work, 0, false, (hipStream_t)stream);
+        float* work = p->d_work + (size_t)h * p->work_frames * p->d_feat;
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(main, p->ev_mlp[h], 0)); // this half is free again
+        int e = launch_pre(p, x + s * (long)p->n_inp * 3, m, work, 0, false, main);
         if (e != 0) return e;
         if (s == 0) snprintf(info, sizeof(info), "%s", p->last_info);
-        e = launch_mlp(p, p->d_work, m, p->d_feat, out + s * (long)p->out_dim, (hipStream_t)stream);
+        HIP_TRY(hipEventRecord(p->ev_feat[h], main));
+        HIP_TRY(hipStreamWaitEvent(p->side, p->ev_feat[h], 0));
+        e = launch_mlp(p, work, m, p->d_feat, out + s * (long)p->out_dim, p->side);
         if (e != 0) return e;
+        HIP_TRY(hipEventRecord(p->ev_mlp[h], p->side));
     }
-    snprintf(p->last_info, sizeof(p->last_info), "%.180s + mlp_mfma_kernel<%s> chunk=%ld", info,
+    for (int h = 0; h < 2 && h < i; ++h) HIP_TRY(hipStreamWaitEvent(main, p->ev_mlp[h], 0)); // join
+    snprintf(p->last_info, sizeof(p->last_info), "%.170s || mlp_mfma_kernel<%s> chunk=%ld", info,
              p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->work_frames);
     return MOLANN_OK;
 }

@@ -32,7 +32,7 @@ class Workload(object):
 
     def __init__(self, name, ref_xyz, features, align=None, mlp_dims=None, use_angle_value=False,
                  frames=1 << 20, noise=0.1, rigid_motion=False, translation=3.0, seed=1234,
-                 mlp_dtype="f32", description=""):
+                 mlp_dtype="f32", description="", kind="forward"):
         self.name = name
         self.ref_xyz = np.ascontiguousarray(ref_xyz, dtype=np.float32)
         self.n_atoms = int(self.ref_xyz.shape[0])
@@ -47,6 +47,7 @@ class Workload(object):
         self.seed = int(seed)
         self.mlp_dtype = mlp_dtype
         self.description = description
+        self.kind = kind          # "forward" (features [+ MLP]) or "align" (AlignmentLayer.forward alone)
 
     # ---- derived sizes -------------------------------------------------------------------
     def feature_dim(self):
@@ -61,6 +62,8 @@ class Workload(object):
         return d
 
     def out_dim(self):
+        if self.kind == "align":
+            return 3 * self.n_atoms
         return self.mlp_dims[-1] if self.mlp_dims else self.feature_dim()
 
     def touched_atoms(self):
@@ -70,7 +73,9 @@ class Workload(object):
         return sorted(s)
 
     def algorithmic_bytes_per_frame(self):
-        """12 * |align U feature atoms| + sizeof(out) * d_out."""
+        """12 * |align U feature atoms| + sizeof(out) * d_out (align: every atom in and out)."""
+        if self.kind == "align":
+            return 24 * self.n_atoms
         return 12 * len(self.touched_atoms()) + 4 * self.out_dim()
 
     def dense_bytes_per_frame(self):
@@ -194,7 +199,12 @@ def _c5():
                     description="5000-atom chain, Kabsch on 312 'CA' + 256 features (d=341) + bf16 MLP [341,512,256,16], 1M frames/GPU")
 
 
-_FACTORIES = {"C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
+def _a3():
+    return Workload("A3", ALA_DIPEPTIDE_XYZ, [], align=ALA_BACKBONE, frames=1 << 20, rigid_motion=True, kind="align",
+                    description="22 atoms, AlignmentLayer.forward alone (Kabsch on 7 backbone atoms, all 22 atoms written back)")
+
+
+_FACTORIES = {"A3": _a3, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
 
 
 def get_workload(name):
@@ -215,6 +225,8 @@ def build_model(w, device=None, seed=0):
     u = Universe(w.ref_xyz)
     input_ag = u.atoms
     alayer = AlignmentLayer(u.atoms_by_number(w.align), input_ag) if w.align is not None else None
+    if w.kind == "align":
+        return alayer.to(device) if device is not None else alayer
     feats = [Feature("f%d" % i, TYPE_NAMES[t], u.atoms_by_number(atoms)) for i, (t, atoms) in enumerate(w.features)]
     pp = PreprocessingANN(alayer, FeatureLayer(feats, input_ag, w.use_angle_value))
     if not w.mlp_dims:

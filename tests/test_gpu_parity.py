@@ -240,3 +240,44 @@ def test_capi_direct_forward_f32(hip_device):
     # stage errors
     assert _capi.lib().molann_align_f32(plan._handle, ctypes.c_void_p(x.data_ptr()), 777,
                                         ctypes.c_void_p(out.data_ptr()), plan._stream()) == _capi.E_STAGE
+
+
+@pytest.mark.parametrize("env", [{"MOLANN_NO_JIT": "1"}, {"MOLANN_NO_JIT": "1", "MOLANN_DEBUG_NO_REGS": "1"}],
+                         ids=["generic_regs", "generic_lds"])
+@pytest.mark.parametrize("name", ["molann_C1", "molann_C3", "features_C2", "features_C3p", "features_C3_val",
+                                  "flayer_permuted_input", "pp_align123_pos12", "molann_C3_relu", "molann_C3_sigmoid"])
+def test_generic_lane_kernels(name, env, hip_device, monkeypatch):
+    """The ahead-of-time lane kernel (what runs when hipRTC is missing), in both of its feature modes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = Case(name)
+    model = build_modules(c, hip_device)
+    got = _run(model, c.x.to(hip_device))
+    pp = model if c.kind == "features" else model.preprocessing_layer
+    info = list((model if c.kind != "features" else pp)._plans().values())[-1].plan.last_launch_info()
+    assert "frames_lane_kernel" in info, info
+    assert ("features_lds" in info) == ("MOLANN_DEBUG_NO_REGS" in env) or "features_regs" not in info
+    assert float((got - c.out_f32).abs().max()) <= c.tolerance_vs_f32()
+
+
+def test_specialised_kernel_is_used_by_default(hip_device):
+    c = Case("molann_C3")
+    model = build_modules(c, hip_device)
+    _run(model, c.x.to(hip_device))
+    info = list(model._plans().values())[-1].plan.last_launch_info()
+    assert "molann_lane_jit" in info, info
+
+
+def test_align_workload_full_size_properties(hip_device):
+    """AlignmentLayer.forward at 1M frames: internal distances are preserved (rigid map) and the align
+    atoms' centroid lands on the origin."""
+    w = wl.get_workload("A3")
+    al = wl.build_model(w, hip_device)
+    x = w.make_frames(1 << 20, device=hip_device, seed=12)
+    with torch.no_grad():
+        a = al(x)
+    d0 = (x[:, 4] - x[:, 18]).norm(dim=1)
+    d1 = (a[:, 4] - a[:, 18]).norm(dim=1)
+    assert float((d0 - d1).abs().max()) <= 2e-5
+    cen = a[:, [i - 1 for i in w.align], :].mean(dim=1)
+    assert float(cen.abs().max()) <= 1e-5
