@@ -281,3 +281,18 @@ def test_align_workload_full_size_properties(hip_device):
     assert float((d0 - d1).abs().max()) <= 2e-5
     cen = a[:, [i - 1 for i in w.align], :].mean(dim=1)
     assert float(cen.abs().max()) <= 1e-5
+
+
+def test_hip_graph_replay_matches_eager(hip_device):
+    from molann_amd.graph import GraphedForward
+    for cfg in ("C1", "C3"):
+        w = wl.get_workload(cfg)
+        model = workload_model(w, hip_device).requires_grad_(False)
+        x0 = w.make_frames(1024, seed=1).to(hip_device)
+        g = GraphedForward(model, x0)
+        for seed in (2, 3):
+            x = w.make_frames(1024, seed=seed).to(hip_device)
+            want = _run(model, x)
+            got = g(x).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(got.cpu(), want), cfg

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: incremental cost of the stages on C3's system at full size (each variant gets its own
+plan-specialised kernel): features only, Kabsch + features, Kabsch + features + MLP."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from molann_amd import workloads as wl
+from molann_amd.ann import AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn
+from molann_amd.atomgroup import Universe
+from molann_amd.feature import Feature
+
+dev = torch.device("cuda:0")
+w = wl.get_workload("C3")
+u = Universe(w.ref_xyz)
+feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number(a)) for i, (t, a) in enumerate(w.features)]
+fl = FeatureLayer(feats, u.atoms)
+al = AlignmentLayer(u.atoms_by_number(w.align), u.atoms)
+torch.manual_seed(0)
+variants = {
+    "features only (4 items)": PreprocessingANN(None, fl),
+    "Kabsch + features": PreprocessingANN(al, fl),
+    "Kabsch + features + MLP[6,32,8]": MolANN(PreprocessingANN(al, fl), create_sequential_nn([6, 32, 8])),
+    "features + MLP[6,32,8] (no Kabsch)": MolANN(PreprocessingANN(None, fl), create_sequential_nn([6, 32, 8])),
+}
+xs = [w.make_frames(w.frames, device=dev, seed=i) for i in range(5)]
+for name, m in variants.items():
+    m = m.to(dev).requires_grad_(False)
+    with torch.no_grad():
+        for i in range(5):
+            m(xs[i % 5])
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(40):
+            m(xs[i % 5])
+        b.record(); b.synchronize()
+    print("%-40s %.1f us / 1M frames   [%s]" % (name, a.elapsed_time(b) / 40 * 1e3, list(m._plans().values())[-1].plan.last_launch_info()[:28]))
