@@ -151,6 +151,23 @@ int molann_forward_f32(molann_plan* plan, const float* x, int64_t n_frames, cons
 int molann_mlp_packed_f32(const molann_plan* plan, const float* f, int64_t n_frames, float* out,
                           molann_stream_t stream);
 
+/* -- backward (the reference relies on torch autograd, incl. through its SVD) -------- */
+
+/* Floats of the parameter-gradient buffer: for every Linear layer dW[J][K] (torch layout) then db[J]. */
+int molann_plan_grad_params_size(const molann_plan* plan);
+
+/* 1 if molann_backward_f32 can serve this plan (see below), else 0. */
+int molann_plan_supports_backward(const molann_plan* plan);
+
+/* Gradients of molann_forward_packed_f32 (plans with an MLP) / molann_features_f32 (plans without) for the
+ * same x: grad_out[N, out_dim] -> grad_x[N, n_inp, 3] (written; zeros for atoms the plan does not touch;
+ * may be NULL) and grad_params (ACCUMULATED into with float atomics, so zero it first; may be NULL).
+ * Nothing is saved from the forward: the kernel recomputes it.  Available for plans served by the
+ * lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU / sigmoid / identity / SiLU /
+ * LeakyReLU; otherwise MOLANN_E_UNSUPPORTED.  Compiled with hipRTC at the first call. */
+int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* grad_x,
+                        float* grad_params, molann_stream_t stream);
+
 /* -- misc ------------------------------------------------------------------------------------- */
 int molann_abi_version(void);
 const char* molann_error_string(int code);
@@ -160,7 +177,8 @@ int molann_plan_last_launch_info(const molann_plan* plan, char* buf, int cap);
 
 /* Diagnostic / test hook: the source of the plan-specialised lane kernel for a description (copied to
  * buf, NUL-terminated, at most cap bytes) and, if do_compile != 0, a hipRTC compile of it for gfx950 (no
- * GPU needed).  Returns the source length; on a compile failure a positive hiprtcResult and the log in buf. */
+ * GPU needed).  do_compile bit 0: compile; bit 1: the backward kernel instead of the forward one.
+ * Returns the source length; on a compile failure a positive hiprtcResult and the log in buf. */
 int molann_debug_jit(const molann_plan_desc* desc, int do_compile, char* buf, int cap);
 
 /* Diagnostic: per-phase shader-clock sums recorded when MOLANN_DEBUG_ABLATE has bit 32 set (see
@@ -172,6 +190,9 @@ int molann_debug_read_stamps(unsigned long long* out8);
 int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9);
 int molann_selftest_feature(int type, int use_angle_value, const float* atoms_xyz, float* out3);
 float molann_selftest_activation(int act, float v);
+int molann_selftest_feature_backward(int type, int use_angle_value, const float* atoms_xyz, const float* g3, float* ga12);
+int molann_selftest_kabsch_backward(const double* H9, const float* R9, const float* GR9, float* GH9);
+float molann_selftest_act_derivative(int act, float z);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (seconds).  Used by __graft_entry__.build()."""
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(os.path.join(_CSRC, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("molann_kernels.hip", "molann_math.h", "molann_lane_jit.inc")) or os.path.getmtime(HEADER_PATH) > os.path.getmtime(LIB_PATH):
+            for f in ("molann_kernels.hip", "molann_math.h", "molann_lane_jit.inc", "molann_lane_bwd.inc")) or os.path.getmtime(HEADER_PATH) > os.path.getmtime(LIB_PATH):
         subprocess.check_call(["make", "-C", _CSRC, "libmolann_hip.so"])
     return LIB_PATH
 
@@ -81,11 +81,17 @@ def lib():
             "molann_forward_f32": (i32, [vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
             "molann_mlp_packed_f32": (i32, [vp, vp, i64, vp, vp]),
             "molann_plan_last_launch_info": (i32, [vp, ctypes.c_char_p, i32]),
+            "molann_plan_grad_params_size": (i32, [vp]),
+            "molann_plan_supports_backward": (i32, [vp]),
+            "molann_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_debug_read_stamps": (i32, [vp]),
             "molann_debug_jit": (i32, [ctypes.POINTER(PlanDesc), i32, ctypes.c_char_p, i32]),
             "molann_selftest_kabsch_rotation": (i32, [vp, ctypes.c_double, vp]),
             "molann_selftest_feature": (i32, [i32, i32, vp, vp]),
             "molann_selftest_activation": (f32, [i32, f32]),
+            "molann_selftest_feature_backward": (i32, [i32, i32, vp, vp, vp]),
+            "molann_selftest_kabsch_backward": (i32, [vp, vp, vp, vp]),
+            "molann_selftest_act_derivative": (f32, [i32, f32]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -207,6 +213,21 @@ class Plan(object):
 
     def mlp_packed(self, f, out):
         return self._run("molann_mlp_packed_f32", f, out, f.shape[0])
+
+    def supports_backward(self):
+        return lib().molann_plan_supports_backward(self._handle) == 1
+
+    def grad_params_size(self):
+        return lib().molann_plan_grad_params_size(self._handle)
+
+    def backward(self, x, grad_out, grad_x, grad_params):
+        """grad_x / grad_params may be None; grad_params is accumulated into."""
+        code = _lib.molann_backward_f32(self._handle, x.data_ptr(), grad_out.data_ptr(), x.shape[0],
+                                        grad_x.data_ptr() if grad_x is not None else None,
+                                        grad_params.data_ptr() if grad_params is not None else None,
+                                        torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_backward_f32")
 
     def last_launch_info(self):
         buf = ctypes.create_string_buffer(256)

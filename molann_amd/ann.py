@@ -10,8 +10,10 @@ in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
     create_sequential_nn(layer_dims, activation)                 ann.py:37-67
 
 There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 tensor that lives
-on a HIP device raises.  Gradients are not implemented on this path yet, so a forward that would
-have to record them raises as well (run it under ``torch.no_grad()``).
+on a HIP device raises.  Gradients (w.r.t. x and the Linear parameters) come from a hand-written backward
+kernel for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32); where that
+kernel does not apply (large frames, wide MLPs, `AlignmentLayer` on its own) a forward that would have to
+record gradients raises NotImplementedError: run it under ``torch.no_grad()``.
 """
 
 import torch
@@ -96,17 +98,60 @@ def _check_input(x, input_atom_num):
         f'Input should be a 3d torch tensor, with sizes [*, {input_atom_num}, 3]. Actual sizes: {x.shape}'
 
 
-def _device_input(x, grad_sources=()):
+def _wants_grad(x, grad_sources=()):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in grad_sources))
+
+
+def _device_input(x, grad_sources=(), backward_ok=False):
     """The tensor the kernels read: float32, on a HIP device, contiguous.  Everything else raises."""
     if not x.is_cuda:
         raise RuntimeError("molann_amd runs on the MI355X only: got a %s tensor (no CPU path; move x and the "
                            "module to a HIP device)" % x.device.type)
     if x.dtype != torch.float32:
         raise TypeError("molann_amd kernels are float32; got %s" % x.dtype)
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in grad_sources)):
-        raise NotImplementedError("the HIP forward path does not record gradients yet: call it under "
+    if not backward_ok and _wants_grad(x, grad_sources):
+        raise NotImplementedError("no backward kernel for this module / plan yet: call it under "
                                   "torch.no_grad() (or freeze the parameters)")
     return x if x.is_contiguous() else x.contiguous()
+
+
+class _PlanFunction(torch.autograd.Function):
+    """forward = one fused launch of the plan; backward = molann_backward_f32 (recomputes the forward per
+    frame, nothing but x is saved).  `params` are the Linear weights/biases in layer order (may be empty)."""
+
+    @staticmethod
+    def forward(ctx, x, entry, with_mlp, *params):
+        plan = entry.plan
+        out = torch.empty((x.shape[0], plan.out_dim if with_mlp else plan.feature_dim), dtype=torch.float32, device=x.device)
+        if with_mlp:
+            plan.forward_packed(x, out)
+        else:
+            plan.features(x, out)
+        ctx.save_for_backward(x)
+        ctx.entry, ctx.shapes = entry, [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        plan = ctx.entry.plan
+        need_x = ctx.needs_input_grad[0]
+        need_p = any(ctx.needs_input_grad[3:])
+        gx = torch.empty_like(x) if need_x else None
+        gp = torch.zeros(plan.grad_params_size(), dtype=torch.float32, device=x.device) if need_p else None
+        g = grad_out.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        with torch.cuda.device(x.device):
+            plan.backward(x, g, gx, gp)
+        grads, off = [], 0
+        for i, shp in enumerate(ctx.shapes):
+            n = 1
+            for d in shp:
+                n *= d
+            grads.append(gp[off:off + n].view(shp) if (need_p and ctx.needs_input_grad[3 + i]) else None)
+            off += n
+        return (gx, None, None) + tuple(grads)
 
 
 def _device_buffer(ref_x, x):
@@ -285,7 +330,7 @@ class FeatureLayer(_PlanOwner, torch.nn.Module):
 
 def _run_features(feature_owner, x, align_layer, plan_owner=None):
     """features (optionally of the aligned frame) through one fused launch."""
-    x = _device_input(x)
+    x = _device_input(x, backward_ok=True)
     spec, uav = _feature_spec(feature_owner)
     owner = plan_owner if plan_owner is not None else feature_owner
 
@@ -296,12 +341,16 @@ def _run_features(feature_owner, x, align_layer, plan_owner=None):
                           ref_x=align_layer.ref_x, features=spec, use_angle_value=uav)
 
     entry = _get_entry(owner, x, "features", build)
-    out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float32, device=x.device)
     if x.shape[0] == 0:
-        return out
+        return torch.empty((0, entry.plan.feature_dim), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         if align_layer is not None:
             entry.sync_ref(_device_buffer(align_layer.ref_x, x))
+        if _wants_grad(x):
+            if not entry.plan.supports_backward():
+                raise NotImplementedError("no backward kernel for this plan (large frames): use torch.no_grad()")
+            return _PlanFunction.apply(x, entry, False)
+        out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float32, device=x.device)
         entry.plan.features(x, out)
     return out
 
@@ -399,10 +448,22 @@ class MolANN(_PlanOwner, torch.nn.Module):
         if al is not None:
             _check_input(x, al.input_atom_num)
         _check_input(x, fl.input_atom_num)
-        x = _device_input(x, grad_sources=st["params"])
-        out = torch.empty((x.shape[0], st["out_dim"]), dtype=torch.float32, device=x.device)
+        x = _device_input(x, grad_sources=st["params"], backward_ok=True)
         if x.shape[0] == 0:
-            return out
+            return torch.empty((0, st["out_dim"]), dtype=torch.float32, device=x.device)
+        if _wants_grad(x, st["params"]):
+            w0 = st["linears"][0].weight
+            if w0.device != x.device or w0.dtype != torch.float32:
+                raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))
+            with torch.cuda.device(x.device):
+                if al is not None:
+                    entry.sync_ref(_device_buffer(al.ref_x, x))
+                entry.sync_mlp(st["linears"])
+                if not entry.plan.supports_backward():
+                    raise NotImplementedError("no backward kernel for this plan (wide MLP / large frames / this "
+                                              "activation): call it under torch.no_grad()")
+                return _PlanFunction.apply(x, entry, True, *st["params"])
+        out = torch.empty((x.shape[0], st["out_dim"]), dtype=torch.float32, device=x.device)
         w0 = st["linears"][0].weight
         if w0.device != x.device or w0.dtype != torch.float32:
             raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))

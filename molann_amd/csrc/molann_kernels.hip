@@ -924,6 +924,11 @@ struct molann_plan {
     hipFunction_t jit_fn;
     int jit_nl;          // Linear layers fused into it (0: features only)
     char jit_note[96];
+    struct JitSpecBox* spec;   // what the specialised kernels are generated from (kept for the lazy backward build)
+    hipModule_t bwd_mod;
+    hipFunction_t bwd_fn;      // backward kernel, compiled at the first molann_backward_f32
+    int bwd_state;             // 0 not tried, 1 ready, -1 unavailable
+    int n_grad_params;         // floats of the parameter-gradient buffer (dW_l[J][K], db_l[J] per layer)
     int n_slots;
     bool regs_mode;
     int* d_slots;
@@ -1079,8 +1084,44 @@ struct JitSpec { // what the specialised kernel is compiled for
 };
 
 constexpr int JIT_MAX_ITEMS = 48, JIT_MAX_SLOTS = 32;
+} // namespace
+struct JitSpecBox { JitSpec j; std::vector<int> kp, jp; std::vector<long> woff; };
+namespace {
+
+std::string jit_preamble(const JitSpec& j);
 
 std::string jit_source(const JitSpec& j) {
+    std::string s = jit_preamble(j);
+    s += "#line 1 \"molann_lane_jit.inc\"\n";
+    s += join_chunks(k_src_molann_lane_jit_inc);
+    return s;
+}
+
+// backward kernel: the forward preamble + where the weights live (fp32 MFMA copy: Wp[Jp][Kp], bias[Jp]) and
+// the layout of the parameter-gradient buffer (torch layout: dW[J][K] then db[J], layer after layer)
+std::string jit_source_bwd(const JitSpecBox& b, int lds_per_wave) {
+    JitSpec j = b.j;
+    j.lds_per_wave = lds_per_wave;
+    std::string s = jit_preamble(j);
+    char t[128];
+    auto arr = [&](const char* name, const std::vector<long>& v) {
+        s += std::string("constexpr int ") + name + "[] = {";
+        for (size_t i = 0; i < v.size(); ++i) { snprintf(t, sizeof(t), "%s%ld", i ? ", " : "", v[i]); s += t; }
+        s += "};\n";
+    };
+    std::vector<long> kp(b.kp.begin(), b.kp.end()), jp(b.jp.begin(), b.jp.end()), woff = b.woff, goff;
+    long g = 0;
+    for (int l = 0; l < j.n_layers; ++l) { goff.push_back(g); g += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1]; }
+    if (kp.empty()) { kp.push_back(1); jp.push_back(1); woff.push_back(0); goff.push_back(0); }
+    arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
+    snprintf(t, sizeof(t), "constexpr int N_PARAMS = %ld;\n", g);
+    s += t;
+    s += "#line 1 \"molann_lane_bwd.inc\"\n";
+    s += join_chunks(k_src_molann_lane_bwd_inc);
+    return s;
+}
+
+std::string jit_preamble(const JitSpec& j) {
     std::string s = "// preamble generated from the plan\n";
     char b[256];
     auto K = [&](const char* name, int v) { snprintf(b, sizeof(b), "constexpr int %s = %d;\n", name, v); s += b; };
@@ -1112,8 +1153,6 @@ std::string jit_source(const JitSpec& j) {
     if (dims.empty()) dims.push_back(j.d_feat);
     while (dims.size() < 2) dims.push_back(1); // the kernel text names DIMS[1] even when NL == 0 discards its use
     A("DIMS", dims);
-    s += "#line 1 \"molann_lane_jit.inc\"\n";
-    s += join_chunks(k_src_molann_lane_jit_inc);
     return s;
 }
 
@@ -1492,6 +1531,13 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         j.wpb = p->geom[0].wpb; j.lds_per_wave = p->geom[0].lds_per_wave; j.fbuf_off = p->geom[0].fbuf_off;
         j.slots = slots; j.items = items_slot;
         if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
+        p->spec = new (std::nothrow) JitSpecBox();
+        if (p->spec) {
+            p->spec->j = j;
+            for (int l = 0; l < j.n_layers; ++l) { p->spec->kp.push_back(p->kp[l]); p->spec->jp.push_back(p->jp[l]); p->spec->woff.push_back(p->moff[l]); }
+            p->n_grad_params = 0;
+            for (int l = 0; l < j.n_layers; ++l) p->n_grad_params += p->dims[l + 1] * p->dims[l] + p->dims[l + 1];
+        }
         std::vector<char> code;
         std::string log;
         const int rc = jit_compile(jit_source(j), code, log);
@@ -1512,6 +1558,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
 int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
+    if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
+    delete p->spec;
     if (p->side) {
         (void)hipStreamSynchronize(p->side);
         for (int h = 0; h < 2; ++h) { (void)hipEventDestroy(p->ev_feat[h]); (void)hipEventDestroy(p->ev_mlp[h]); }
@@ -1640,6 +1688,62 @@ int molann_forward_f32(molann_plan* p, const float* x, int64_t n, const float* c
     return molann_forward_packed_f32(p, x, n, out, stream);
 }
 
+int molann_plan_grad_params_size(const molann_plan* p) { return p ? p->n_grad_params : MOLANN_E_NULL; }
+
+int molann_plan_supports_backward(const molann_plan* p) {
+    if (!p) return MOLANN_E_NULL;
+    if (!p->spec || p->n_items <= 0 || p->bwd_state < 0 || !rtc_api()->ok) return 0;
+    if (p->n_layers > 0 && !p->fused_mlp) return 0;
+    const int act = p->act;
+    if (p->n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return 0;
+    return 1;
+}
+
+// dL/dx and dL/d(parameters) of molann_forward_packed_f32 / molann_features_f32 for the same x.
+int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, int64_t n, float* grad_x, float* grad_params,
+                        molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !grad_out) return MOLANN_E_NULL;
+    if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
+    const int act = p->act;
+    if (p->spec->j.n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return MOLANN_E_UNSUPPORTED;
+    if (p->n_layers > 0 && !p->fused_mlp) return MOLANN_E_UNSUPPORTED; // wide MLPs: not yet
+    if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    molann_plan::LaneGeom g;
+    lane_geometry(g, 64 * p->n_inp * 12, 1);
+    if (!g.ok) return MOLANN_E_UNSUPPORTED;
+    if (p->bwd_state == 0) {
+        std::vector<char> code;
+        std::string log;
+        JitSpecBox b = *p->spec;
+        b.j.wpb = g.wpb;
+        const int rc = jit_compile(jit_source_bwd(b, g.lds_per_wave), code, log);
+        if (rc == 0 && hipModuleLoadData(&p->bwd_mod, code.data()) == hipSuccess &&
+            hipModuleGetFunction(&p->bwd_fn, p->bwd_mod, "molann_lane_bwd") == hipSuccess) {
+            p->bwd_state = 1;
+        } else {
+            p->bwd_state = -1;
+            if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann backward jit failed rc=%d\n%s\n", rc, log.c_str());
+        }
+    }
+    if (p->bwd_state != 1) return MOLANN_E_UNSUPPORTED;
+    const long n_tiles = (n + 63) / 64;
+    int bpc = (int)(163840 / ((long)g.wpb * g.lds_per_wave));
+    if (bpc < 1) bpc = 1;
+    if (bpc * g.wpb > 8) bpc = std::max(1, 8 / g.wpb);
+    const int grid = grid_for(p, n_tiles, g.wpb, bpc);
+    struct { const float* x; const float* gout; const double* ref64; const float* wnat; float* gx; float* gp; long n; int x_wide; } ka =
+        {x, grad_out, p->d_ref64, (const float*)p->d_wmfma, grad_x, grad_params, (long)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0};
+    size_t ksz = sizeof(ka);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+    const hipError_t le = hipModuleLaunchKernel(p->bwd_fn, grid, 1, 1, 64 * g.wpb, 1, 1, (unsigned)((size_t)g.wpb * g.lds_per_wave),
+                                                (hipStream_t)stream, nullptr, cfg);
+    snprintf(p->last_info, sizeof(p->last_info), "molann_lane_bwd (plan-specialised) grid=%d block=%d", grid, 64 * g.wpb);
+    return (int)le;
+}
+
 // diagnostic / test hook: generate (and optionally compile, needs no GPU) the plan-specialised kernel
 // source for a description.  Returns the source length, or a negative MOLANN_E_* / positive hiprtcResult.
 int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int cap) {
@@ -1678,9 +1782,24 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     lane_geometry(g, 64 * d->n_inp * 12, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
     if (!g.ok) return MOLANN_E_UNSUPPORTED;
     j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
-    const std::string src = jit_source(j);
+    std::string src = jit_source(j);
+    if (do_compile & 2) { // the backward kernel of the same plan
+        JitSpecBox b;
+        b.j = j;
+        long off = 0;
+        for (int l = 0; l < j.n_layers; ++l) {
+            const int kp = ceil_to(j.dims[l], 16), jp = ceil_to(j.dims[l + 1], 16);
+            b.kp.push_back(kp); b.jp.push_back(jp); b.woff.push_back(off);
+            off += (long)jp * kp + jp;
+            off = (off + 3) & ~3l;
+        }
+        molann_plan::LaneGeom gb;
+        lane_geometry(gb, 64 * d->n_inp * 12, 1);
+        b.j.wpb = gb.wpb;
+        src = jit_source_bwd(b, gb.lds_per_wave);
+    }
     if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", src.c_str());
-    if (do_compile) {
+    if (do_compile & 1) {
         std::vector<char> code;
         std::string log;
         const int rc = jit_compile(src, code, log);
@@ -1728,5 +1847,33 @@ int molann_selftest_feature(int type, int use_angle_value, const float* a, float
 }
 
 float molann_selftest_activation(int act, float v) { return apply_activation(act, v); }
+
+int molann_selftest_feature_backward(int type, int use_angle_value, const float* a, const float* g3, float* ga12) {
+    if (!a || !g3 || !ga12) return MOLANN_E_NULL;
+    int it;
+    if (type == MOLANN_FEAT_ANGLE) it = use_angle_value ? IT_ANGLE_VAL : IT_ANGLE_COS;
+    else if (type == MOLANN_FEAT_BOND) it = IT_BOND;
+    else if (type == MOLANN_FEAT_DIHEDRAL) it = use_angle_value ? IT_DIHEDRAL_VAL : IT_DIHEDRAL_CS;
+    else if (type == MOLANN_FEAT_POSITION) it = IT_POSITION;
+    else return MOLANN_E_FEATURE;
+    V3 g[4] = {v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0)};
+    const float gg[3] = {g3[0], g3[1], g3[2]};
+    eval_item_backward(it, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), gg, g[0],
+                       g[1], g[2], g[3]);
+    for (int i = 0; i < 4; ++i) { ga12[3 * i] = g[i].x; ga12[3 * i + 1] = g[i].y; ga12[3 * i + 2] = g[i].z; }
+    return MOLANN_OK;
+}
+
+int molann_selftest_kabsch_backward(const double* H9, const float* R9, const float* GR9, float* GH9) {
+    if (!H9 || !R9 || !GR9 || !GH9) return MOLANN_E_NULL;
+    double h[9];
+    float r[9], gr[9], gh[9];
+    for (int i = 0; i < 9; ++i) { h[i] = H9[i]; r[i] = R9[i]; gr[i] = GR9[i]; }
+    kabsch_rotation_backward(h, r, gr, gh);
+    for (int i = 0; i < 9; ++i) GH9[i] = gh[i];
+    return MOLANN_OK;
+}
+
+float molann_selftest_act_derivative(int act, float z) { return act_derivative(act, z, apply_activation(act, z)); }
 
 } // extern "C"

@@ -286,4 +286,133 @@ MOLANN_HD V3 rotate(V3 p, const float (&R)[9]) {
               fmaf(p.z, R[8], fmaf(p.y, R[5], p.x * R[2])));
 }
 
+// =================================================================================================
+// reverse mode (backward of the path; the reference relies on torch autograd for all of it)
+// =================================================================================================
+MOLANN_HD V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+MOLANN_HD void axpy(V3& acc, float s, V3 a) { acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y); acc.z = fmaf(s, a.z, acc.z); }
+
+// Gradient of one feature item with respect to its (aligned) atoms: g[] is dL/d(output columns of the item),
+// ga0..ga3 are ACCUMULATED into.  Mirrors eval_item; formulas are the reverse-mode of ann.py:323-354.
+MOLANN_HD void eval_item_backward(int type, V3 a0, V3 a1, V3 a2, V3 a3, const float (&g)[3], V3& ga0, V3& ga1, V3& ga2,
+                                  V3& ga3) {
+    switch (type) {
+    case IT_BOND: {
+        const V3 r = a1 - a0;
+        const float d2 = dot(r, r);
+        const float inv = d2 > 0.0f ? fast_rsq(d2) : 0.0f; // |r| = 0: subgradient 0
+        axpy(ga1, g[0] * inv, r);
+        axpy(ga0, -g[0] * inv, r);
+        return;
+    }
+    case IT_ANGLE_COS:
+    case IT_ANGLE_VAL: {
+        const V3 u = a0 - a1, v = a2 - a1;
+        const float uu = dot(u, u), vv = dot(v, v), uv = dot(u, v);
+        const float inv_uv = fast_rsq(uu * vv); // 1 / (|u||v|)
+        const float c = uv * inv_uv;
+        float gc = g[0];
+        if (type == IT_ANGLE_VAL) gc = -g[0] * fast_rsq(fmaxf(1.0f - c * c, 1e-30f)); // d acos(c) = -dc / sqrt(1 - c^2)
+        // dc/du = v/(|u||v|) - c u/|u|^2 ,  dc/dv = u/(|u||v|) - c v/|v|^2
+        V3 gu = v3(0.f, 0.f, 0.f), gv = v3(0.f, 0.f, 0.f);
+        axpy(gu, gc * inv_uv, v); axpy(gu, -gc * c * fast_rcp(uu), u);
+        axpy(gv, gc * inv_uv, u); axpy(gv, -gc * c * fast_rcp(vv), v);
+        ga0 = ga0 + gu;
+        ga2 = ga2 + gv;
+        ga1 = ga1 - (gu + gv);
+        return;
+    }
+    case IT_DIHEDRAL_CS:
+    case IT_DIHEDRAL_VAL: {
+        const V3 r12 = a1 - a0, r23 = a2 - a1, r34 = a3 - a2;
+        const V3 n1 = cross(r12, r23), n2 = cross(r23, r34);
+        const float L2 = dot(r23, r23);
+        const float L = fast_sqrt(L2);
+        const float n1r34 = dot(n1, r34);
+        const float C = dot(n1, n2), S = n1r34 * L;
+        const float rad2 = fmaf(C, C, S * S);
+        float gC, gS;
+        if (type == IT_DIHEDRAL_CS) { // outputs (C, S) / rad
+            const float inv_rad = fast_rsq(rad2);
+            const float proj = (g[0] * C + g[1] * S) * inv_rad * inv_rad * inv_rad;
+            gC = g[0] * inv_rad - proj * C;
+            gS = g[1] * inv_rad - proj * S;
+        } else { // atan2(S, C): d phi = (C dS - S dC) / rad^2
+            const float inv_rad2 = fast_rcp(rad2);
+            gC = -g[0] * S * inv_rad2;
+            gS = g[0] * C * inv_rad2;
+        }
+        // C = n1.n2 ; S = (n1.r34) L
+        V3 gn1 = gC * n2; axpy(gn1, gS * L, r34);
+        const V3 gn2 = gC * n1;
+        V3 gr34 = (gS * L) * n1;
+        V3 gr23 = (L > 0.0f ? gS * n1r34 * fast_rcp(L) : 0.0f) * r23;
+        // n1 = r12 x r23 ; n2 = r23 x r34      (n = a x b  =>  ga = b x gn , gb = gn x a)
+        const V3 gr12 = cross(r23, gn1);
+        gr23 = gr23 + cross(gn1, r12) + cross(r34, gn2);
+        gr34 = gr34 + cross(gn2, r23);
+        ga0 = ga0 - gr12;
+        ga1 = ga1 + (gr12 - gr23);
+        ga2 = ga2 + (gr23 - gr34);
+        ga3 = ga3 + gr34;
+        return;
+    }
+    default: // IT_POSITION
+        ga0 = ga0 + v3(g[0], g[1], g[2]);
+        return;
+    }
+}
+
+// Derivative of the activation expressed with its OUTPUT h (and input z where the output is not enough).
+MOLANN_HD float act_derivative(int act, float z, float h) {
+    switch (act) {
+    case 0: return fmaf(-h, h, 1.0f);          // tanh' = 1 - tanh^2
+    case 1: return z > 0.0f ? 1.0f : 0.0f;     // ReLU
+    case 2: return h * (1.0f - h);             // sigmoid' = s (1 - s)
+    case 3: return 1.0f;                       // identity
+    case 5: { const float s = act_sigmoid(z); return s * fmaf(z, 1.0f - s, 1.0f); } // SiLU' = s (1 + z (1 - s))
+    case 7: return z > 0.0f ? 1.0f : 0.01f;    // LeakyReLU
+    default: return 1.0f;
+    }
+}
+
+// Backward of kabsch_rotation: given H, the rotation R it produced and G_R = dL/dR, returns G_H = dL/dH.
+// With S = R^T H (symmetric at the optimum) a perturbation dH turns R by dR = R [w]x where
+// (tr(S) I - S) w = vee(R^T dH - dH^T R); hence G_H = R [n]x, n = (tr(S) I - S)^-1 vee(M - M^T), M = R^T G_R.
+// ([v]x = cross-product matrix of v.)  fp64: 3x3 products and one 3x3 symmetric solve.
+MOLANN_HD void kabsch_rotation_backward(const double (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
+    double S[9], M[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double s = 0.0, m = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s = fma((double)R[3 * k + a], H[3 * k + b], s); m = fma((double)R[3 * k + a], (double)GR[3 * k + b], m); }
+            S[3 * a + b] = s;
+            M[3 * a + b] = m;
+        }
+    const double s01 = 0.5 * (S[1] + S[3]), s02 = 0.5 * (S[2] + S[6]), s12 = 0.5 * (S[5] + S[7]);
+    const double tr = S[0] + S[4] + S[8];
+    // B = tr I - S  (symmetric)
+    const double b00 = tr - S[0], b11 = tr - S[4], b22 = tr - S[8], b01 = -s01, b02 = -s02, b12 = -s12;
+    const double m0 = M[7] - M[5], m1 = M[2] - M[6], m2 = M[3] - M[1]; // vee(M - M^T)
+    // n = B^-1 m by the adjugate
+    const double c00 = b11 * b22 - b12 * b12, c01 = b02 * b12 - b01 * b22, c02 = b01 * b12 - b02 * b11;
+    const double c11 = b00 * b22 - b02 * b02, c12 = b01 * b02 - b00 * b12, c22 = b00 * b11 - b01 * b01;
+    const double det = b00 * c00 + b01 * c01 + b02 * c02;
+    const double inv = (det > 1e-300 || det < -1e-300) ? 1.0 / det : 0.0; // ill-defined rotation: no gradient through R
+    const double n0 = (c00 * m0 + c01 * m1 + c02 * m2) * inv;
+    const double n1 = (c01 * m0 + c11 * m1 + c12 * m2) * inv;
+    const double n2 = (c02 * m0 + c12 * m1 + c22 * m2) * inv;
+    // G_H = R [n]x ,  [n]x = [[0,-n2,n1],[n2,0,-n0],[-n1,n0,0]]
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double r0 = R[3 * a], r1 = R[3 * a + 1], r2 = R[3 * a + 2];
+        GH[3 * a + 0] = (float)(r1 * n2 - r2 * n1);
+        GH[3 * a + 1] = (float)(r2 * n0 - r0 * n2);
+        GH[3 * a + 2] = (float)(r0 * n1 - r1 * n0);
+    }
+}
+
 } // namespace molann

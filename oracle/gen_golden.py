@@ -150,6 +150,57 @@ def noisy(ref_xyz, n, sigma, seed, rigid=False, translation=3.0, reflect_every=0
     return x
 
 
+def grad_case(name, u, x, input_numbers, features, align, mlp_dims, use_angle_value=False, seed=11):
+    """Gradients of sum(out * G) from the REFERENCE's autograd (fp32 and its .double() copy)."""
+    import copy
+    input_ag, feats, flayer, alayer, nn = build_reference_model(u, input_numbers, list(features), align, mlp_dims, use_angle_value)
+    model = MolANN(PreprocessingANN(alayer, flayer), nn) if nn is not None else PreprocessingANN(alayer, flayer)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    rec = {}
+    G = None
+    for tag, m, xx in (("f32", model, x.clone()), ("f64", copy.deepcopy(model).double(), x.double())):
+        xx.requires_grad_(True)
+        out = m(xx)
+        if G is None:
+            G = torch.randn(out.shape, generator=g)
+        (out * G.to(out.dtype)).sum().backward()
+        rec["gx_" + tag] = xx.grad.numpy()
+        for i, prm in enumerate(m.parameters()):
+            rec["gp%d_%s" % (i, tag)] = prm.grad.numpy()
+        rec["out_" + tag] = out.detach().numpy()
+    rec.update(x=x.numpy(), G=G.numpy(), n_inp=np.int64(len(input_ag)), use_angle_value=np.bool_(use_angle_value),
+               feat_types=np.asarray([t for t, _ in features], dtype=np.int64))
+    flat, ptr = csr([a for _, a in features])
+    rec["feat_numbers"], rec["feat_ptr"] = flat, ptr
+    if align is not None:
+        rec["align_numbers"] = np.asarray(align, dtype=np.int64)
+    if nn is not None:
+        rec["mlp_dims"] = np.asarray(mlp_dims, dtype=np.int64)
+        for i, lin in enumerate([m for m in nn if isinstance(m, torch.nn.Linear)]):
+            rec["W%d" % i] = lin.weight.detach().numpy()
+            rec["b%d" % i] = lin.bias.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("%-24s gx %s  max|gx32-gx64| = %.3g" % (name, rec["gx_f32"].shape, np.abs(rec["gx_f32"] - rec["gx_f64"]).max()))
+
+
+def grad_main():
+    """Gradient golden vectors only (files grad_*.npz); the forward cases are left untouched."""
+    os.makedirs(OUT, exist_ok=True)
+    pdb = read_pdb_xyz("/root/reference/test/alanine-dipeptide-vacuum.pdb")
+    u = Universe(pdb)
+    all22 = list(range(1, 23))
+    for cname in ("C1", "C3"):
+        w = wl.get_workload(cname)
+        grad_case("grad_molann_%s" % cname, u, w.make_frames(128, seed=21), all22, w.features, w.align, w.mlp_dims)
+    w = wl.get_workload("C3")
+    grad_case("grad_features_C3_val", u, w.make_frames(128, seed=22), all22, w.features, w.align, None, use_angle_value=True)
+    w = wl.get_workload("C3p")
+    grad_case("grad_features_C3p", u, w.make_frames(128, seed=23), all22, w.features, w.align, None)
+    w = wl.get_workload("C2")
+    grad_case("grad_features_C2", u, w.make_frames(128, seed=24), all22, w.features, None, None)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pdb = read_pdb_xyz("/root/reference/test/alanine-dipeptide-vacuum.pdb")
@@ -326,4 +377,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--grads" in sys.argv:
+        grad_main()
+    else:
+        main()

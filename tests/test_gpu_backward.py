@@ -1,0 +1,149 @@
+"""Backward of the HIP path (molann_backward_f32 through torch.autograd) against (i) the reference's own
+autograd results (tests/golden/grad_*.npz, written by oracle/gen_golden.py --grads) and (ii) torch autograd
+through the fp64 oracle on fresh batches."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN_DIR
+from molann_amd import workloads as wl
+from molann_amd.ann import AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn
+from molann_amd.atomgroup import Universe
+from molann_amd.feature import Feature
+from oracle import molann_oracle as mo
+
+pytestmark = pytest.mark.gpu
+U = Universe(wl.ALA_DIPEPTIDE_XYZ)
+
+
+def _model_from_golden(d, dev):
+    ptr = d["feat_ptr"]
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[int(t)], U.atoms_by_number(d["feat_numbers"][ptr[i]:ptr[i + 1]].tolist()))
+             for i, t in enumerate(d["feat_types"].tolist())]
+    al = AlignmentLayer(U.atoms_by_number(d["align_numbers"].tolist()), U.atoms) if "align_numbers" in d else None
+    pp = PreprocessingANN(al, FeatureLayer(feats, U.atoms, bool(d["use_angle_value"])))
+    if "mlp_dims" not in d:
+        return pp.to(dev)
+    nn = create_sequential_nn(d["mlp_dims"].tolist())
+    lins = [m for m in nn if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for i, lin in enumerate(lins):
+            lin.weight.copy_(torch.from_numpy(d["W%d" % i]))
+            lin.bias.copy_(torch.from_numpy(d["b%d" % i]))
+    return MolANN(pp, nn).to(dev)
+
+
+def _close(got, ref32, ref64, what):
+    """within 1e-4 (relative to the gradient's scale) of the fp64 reference, or no further from it than twice
+    the reference's own fp32 run"""
+    scale = max(1e-3, float(np.abs(ref64).max()))
+    err = float(np.abs(got.astype(np.float64) - ref64).max())
+    own = float(np.abs(ref32.astype(np.float64) - ref64).max())
+    assert err <= max(1e-4 * scale, 2.0 * own), (what, err, own, scale)
+
+
+@pytest.mark.parametrize("name", ["grad_molann_C1", "grad_molann_C3", "grad_features_C2", "grad_features_C3_val",
+                                  "grad_features_C3p"])
+def test_gradients_match_reference_autograd(name, hip_device):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    model = _model_from_golden(d, hip_device)
+    x = torch.from_numpy(d["x"]).to(hip_device).requires_grad_(True)
+    out = model(x)
+    assert out.requires_grad
+    _close(out.detach().cpu().numpy(), d["out_f32"], d["out_f64"], "forward")
+    (out * torch.from_numpy(d["G"]).to(hip_device)).sum().backward()
+    torch.cuda.synchronize()
+    _close(x.grad.cpu().numpy(), d["gx_f32"], d["gx_f64"], "grad_x")
+    for i, p in enumerate(model.parameters()):
+        _close(p.grad.cpu().numpy(), d["gp%d_f32" % i], d["gp%d_f64" % i], "param %d" % i)
+
+
+def _oracle_grads(w, model, x, G, act="tanh"):
+    feats = [(t, [a - 1 for a in atoms]) for t, atoms in w.features]
+    al = [a - 1 for a in w.align] if w.align is not None else None
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[[a - 1 for a in w.align]])).double() if al else None
+    xx = x.detach().cpu().double().requires_grad_(True)
+    if w.mlp_dims:
+        lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+        ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+        bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+        out = mo.molann_forward(xx, feats, ws, bs, w.use_angle_value, al, ref_x, act)
+        prm = [t for pair in zip(ws, bs) for t in pair]
+    else:
+        out = mo.preprocessing_forward(xx, feats, w.use_angle_value, al, ref_x)
+        prm = []
+    (out * G.double()).sum().backward()
+    return xx.grad, [p.grad for p in prm]
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C3", "C3p"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_gradients_vs_fp64_oracle(cfg, n, hip_device):
+    w = wl.get_workload(cfg)
+    model = wl.build_model(w, hip_device)
+    x = w.make_frames(n, seed=300 + n).to(hip_device).requires_grad_(True)
+    g = torch.Generator().manual_seed(n)
+    G = torch.randn((n, w.out_dim()), generator=g)
+    out = model(x)
+    (out * G.to(hip_device)).sum().backward()
+    gx_want, gp_want = _oracle_grads(w, model, x, G)
+    scale = max(1e-3, float(gx_want.abs().max()))
+    assert float((x.grad.cpu().double() - gx_want).abs().max()) <= 2e-4 * scale
+    untouched = [i for i in range(w.n_atoms) if (i + 1) not in w.touched_atoms()]
+    if untouched:
+        assert float(x.grad[:, untouched].abs().max()) == 0.0      # atoms the plan never reads
+    for p, want in zip(model.parameters(), gp_want):
+        s = max(1e-3, float(want.abs().max()))
+        assert float((p.grad.cpu().double() - want).abs().max()) <= 2e-4 * s
+
+
+@pytest.mark.parametrize("act", [torch.nn.ReLU, torch.nn.Sigmoid, torch.nn.SiLU, torch.nn.LeakyReLU])
+def test_gradients_other_activations(act, hip_device):
+    w = wl.get_workload("C3")
+    base = wl.build_model(w, hip_device)
+    torch.manual_seed(4)
+    model = MolANN(base.preprocessing_layer, create_sequential_nn([6, 20, 12, 4], activation=act()).to(hip_device))
+    x = w.make_frames(500, seed=8).to(hip_device).requires_grad_(True)
+    G = torch.randn((500, 4), generator=torch.Generator().manual_seed(1))
+    (model(x) * G.to(hip_device)).sum().backward()
+    # torch autograd on the same device modules as the check of the MLP part: features from the HIP path (no grad)
+    with torch.no_grad():
+        f = base.preprocessing_layer(x.detach())
+    f = f.double().cpu().requires_grad_(True)
+    import copy
+    nn64 = copy.deepcopy(model.ann_layers).double().cpu()
+    (nn64(f) * G.double()).sum().backward()
+    for p, q in zip(model.ann_layers.parameters(), nn64.parameters()):
+        s = max(1e-3, float(q.grad.abs().max()))
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * s, act.__name__
+
+
+def test_training_step_decreases_loss(hip_device):
+    """A few optimiser steps through the HIP forward + backward (weights repacked after every step)."""
+    w = wl.get_workload("C3")
+    model = wl.build_model(w, hip_device)
+    x = w.make_frames(4096, seed=2).to(hip_device)
+    target = torch.randn((4096, 8), generator=torch.Generator().manual_seed(3)).to(hip_device) * 0.1
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = ((model(x) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_plans_without_a_backward_kernel_raise(hip_device):
+    w = wl.get_workload("C3")
+    al = wl.build_model(wl.get_workload("A3"), hip_device)
+    x = w.make_frames(8).to(hip_device).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        al(x)                                           # AlignmentLayer on its own: not yet
+    big = wl.get_workload("C4")
+    with pytest.raises(NotImplementedError):
+        wl.build_model(big, hip_device)(big.make_frames(2).to(hip_device))   # large frames, parameters need grad

@@ -97,3 +97,70 @@ def test_kabsch_rotation_degenerate_inputs_are_finite():
         assert L.molann_selftest_kabsch_rotation(_ptr(H), 1.0, _ptr(R)) == 0
         assert np.isfinite(R).all()
         assert abs(np.linalg.det(R.reshape(3, 3).astype(np.float64)) - 1.0) < 1e-5
+
+
+# ---- reverse mode: the analytic gradients against torch autograd of the oracle (fp64) ----------------------
+@pytest.mark.parametrize("type_id,n_atoms", [(0, 3), (1, 2), (2, 4), (3, 1)])
+@pytest.mark.parametrize("uav", [False, True])
+def test_feature_backward_matches_autograd(type_id, n_atoms, uav):
+    g = torch.Generator().manual_seed(100 + 10 * type_id + uav)
+    L = _capi.lib()
+    for i in range(100):
+        x = (torch.randn((1, n_atoms, 3), generator=g) * 1.5).double().requires_grad_(True)
+        f = mo.feature_forward(x, type_id, list(range(n_atoms)), uav)
+        gf = torch.randn(f.shape, generator=g).double()
+        (f * gf).sum().backward()
+        want = x.grad[0].numpy()
+        a = np.zeros(12, np.float32); a[:3 * n_atoms] = x.detach().numpy().reshape(-1)
+        g3 = np.zeros(3, np.float32); g3[:gf.numel()] = gf.numpy().reshape(-1)
+        ga = np.zeros(12, np.float32)
+        assert L.molann_selftest_feature_backward(type_id, int(uav), _ptr(a), _ptr(g3), _ptr(ga)) == 0
+        got = ga.reshape(4, 3)[:n_atoms]
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.allclose(got, want, atol=2e-5 * scale, rtol=2e-5), (i, got, want)
+
+
+def test_kabsch_backward_matches_autograd():
+    """G_H from the closed form equals autograd through the SVD formula (ann.py:188-195) in fp64."""
+    g = torch.Generator().manual_seed(5)
+    L = _capi.lib()
+    for i in range(200):
+        a = int(torch.randint(3, 9, (1,), generator=g))
+        ref = torch.randn((a, 3), generator=g).double() * 2
+        ref = ref - ref.mean(0)
+        P = (ref @ wl_q(torch.randn((1, 4), generator=g))[0].double() + 0.2 * torch.randn((a, 3), generator=g).double())
+        if i % 4 == 1:
+            P[:, 2] *= -1                      # reflection branch
+        P = P - P.mean(0)
+        H = (P.T @ ref).requires_grad_(True)
+        u, s, vh = torch.linalg.svd(H)
+        d = torch.sign(torch.linalg.det(u @ vh)).detach()
+        R = u @ torch.diag(torch.stack([torch.ones(()).double(), torch.ones(()).double(), d])) @ vh
+        GR = torch.randn((3, 3), generator=g).double()
+        (R * GR).sum().backward()
+        sv = s.detach().numpy()
+        if (sv[1] + float(d) * sv[2]) / sv[0] < 5e-2:
+            continue                           # nearly ill-defined rotation: derivative blows up, not compared
+        Hn = np.ascontiguousarray(H.detach().numpy().reshape(9))
+        Rn = np.ascontiguousarray(R.detach().numpy().reshape(9).astype(np.float32))
+        GRn = np.ascontiguousarray(GR.numpy().reshape(9).astype(np.float32))
+        GH = np.zeros(9, np.float32)
+        assert L.molann_selftest_kabsch_backward(_ptr(Hn), _ptr(Rn), _ptr(GRn), _ptr(GH)) == 0
+        want = H.grad.numpy().reshape(9)
+        assert np.allclose(GH, want, atol=1e-5 * max(1.0, np.abs(want).max()), rtol=1e-4), (i, GH, want)
+
+
+def wl_q(q):
+    from molann_amd import workloads as wl
+    return wl.quaternion_to_matrix(q / q.norm(dim=1, keepdim=True))
+
+
+@pytest.mark.parametrize("code,fn", [(0, torch.tanh), (1, torch.relu), (2, torch.sigmoid), (5, torch.nn.functional.silu),
+                                     (7, torch.nn.functional.leaky_relu)])
+def test_activation_derivatives(code, fn):
+    zs = torch.linspace(-6, 6, 241).double()
+    zs = zs[zs.abs() > 1e-3].requires_grad_(True)
+    fn(zs).sum().backward()
+    L = _capi.lib()
+    got = np.array([L.molann_selftest_act_derivative(code, float(v)) for v in zs.detach().tolist()])
+    assert np.allclose(got, zs.grad.numpy(), atol=2e-6)
