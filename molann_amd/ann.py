@@ -267,10 +267,21 @@ class AlignmentLayer(_PlanOwner, torch.nn.Module):
 
     def forward(self, x):
         _check_input(x, self.input_atom_num)
-        x = _device_input(x)
-        out = torch.empty_like(x)
+        x = _device_input(x, backward_ok=True)
         if x.shape[0] == 0:
-            return out
+            return torch.empty_like(x)
+        if _wants_grad(x):
+            # the aligned frame == alignment + one position item per atom: that plan has a backward kernel
+            def build():
+                return _capi.Plan(self.input_atom_num, align_idx=self._local_align_atom_indices, ref_x=self.ref_x,
+                                  features=[(_capi.FEAT_POSITION, list(range(self.input_atom_num)))])
+            entry = _get_entry(self, x, "align_grad", build)
+            with torch.cuda.device(x.device):
+                entry.sync_ref(_device_buffer(self.ref_x, x))
+                if not entry.plan.supports_backward():
+                    raise NotImplementedError("no backward kernel for this alignment plan (large frames): use torch.no_grad()")
+                return _PlanFunction.apply(x, entry, False).view(x.shape[0], self.input_atom_num, 3)
+        out = torch.empty_like(x)
         with torch.cuda.device(x.device):
             self._entry(x).plan.align(x, out)
         return out

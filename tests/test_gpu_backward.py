@@ -138,12 +138,24 @@ def test_training_step_decreases_loss(hip_device):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
+def test_alignment_layer_gradient(hip_device):
+    """AlignmentLayer on its own: gradient of the aligned frame w.r.t. x (through the rotation)."""
+    w = wl.get_workload("A3")
+    al = wl.build_model(w, hip_device)
+    x = w.make_frames(300, seed=17).to(hip_device).requires_grad_(True)
+    G = torch.randn((300, 22, 3), generator=torch.Generator().manual_seed(2))
+    y = al(x)
+    with torch.no_grad():
+        assert torch.allclose(y, al(x.detach()), atol=1e-6)       # same values as the no-grad kernel
+    (y * G.to(hip_device)).sum().backward()
+    xx = x.detach().cpu().double().requires_grad_(True)
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[[a - 1 for a in w.align]])).double()
+    (mo.align_forward(xx, [a - 1 for a in w.align], ref_x) * G.double()).sum().backward()
+    scale = float(xx.grad.abs().max())
+    assert float((x.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * scale
+
+
 def test_plans_without_a_backward_kernel_raise(hip_device):
-    w = wl.get_workload("C3")
-    al = wl.build_model(wl.get_workload("A3"), hip_device)
-    x = w.make_frames(8).to(hip_device).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        al(x)                                           # AlignmentLayer on its own: not yet
     big = wl.get_workload("C4")
     with pytest.raises(NotImplementedError):
         wl.build_model(big, hip_device)(big.make_frames(2).to(hip_device))   # large frames, parameters need grad
