@@ -296,3 +296,16 @@ def test_hip_graph_replay_matches_eager(hip_device):
             got = g(x).clone()
             torch.cuda.synchronize()
             assert torch.equal(got.cpu(), want), cfg
+
+
+def test_host_trajectory_streamer(hip_device):
+    """Pinned double-buffered H2D/D2H around the forward gives the same rows as one resident batch."""
+    from molann_amd.stream import stream_forward
+    w = wl.get_workload("C3")
+    model = workload_model(w, hip_device).requires_grad_(False)
+    x = w.make_frames(10000, seed=31)
+    want = _run(model, x.to(hip_device)).numpy()
+    for chunk in (1024, 4096, 10000, 1 << 20):
+        got = stream_forward(model, x.numpy(), chunk_frames=chunk, device=hip_device)
+        assert got.shape == want.shape and np.array_equal(got, want), chunk
+    assert stream_forward(model, x.numpy()[:0], device=hip_device).shape == (0, 8)
