@@ -887,6 +887,21 @@ __global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ ds
 
 inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
+// diagnostic switches, read once per process (never on the launch path)
+struct DebugEnv {
+    int ablate, lds_pad, wave_bpc;
+    DebugEnv() {
+        const char* e;
+        ablate = (e = getenv("MOLANN_DEBUG_ABLATE")) ? atoi(e) : 0;
+        lds_pad = (e = getenv("MOLANN_DEBUG_LDS_PAD")) ? atoi(e) : 0;
+        wave_bpc = (e = getenv("MOLANN_WAVE_BPC")) ? atoi(e) : 0;
+    }
+};
+const DebugEnv& debug_env() {
+    static const DebugEnv env;
+    return env;
+}
+
 } // namespace
 
 // =============================================================================================
@@ -1030,8 +1045,7 @@ void fill_pre_args(const molann_plan* p, PreArgs& a, long n_frames, int mode, in
     a.act = p->act;
     for (int i = 0; i <= p->n_layers; ++i) a.dims[i] = p->dims[i];
     a.out_vec4 = (a.out_wide && (a.out_cols & 3) == 0) ? 1 : 0;
-    const char* dbg = getenv("MOLANN_DEBUG_ABLATE");
-    a.ablate = dbg ? atoi(dbg) : 0;
+    a.ablate = debug_env().ablate;
 }
 
 
@@ -1128,8 +1142,7 @@ std::string jit_preamble(const JitSpec& j) {
     K("N_INP", j.n_inp); K("N_ALIGN", j.n_align); K("N_SLOTS", (int)j.slots.size()); K("N_ITEMS", (int)j.items.size());
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
-    const char* dbg = getenv("MOLANN_DEBUG_ABLATE");
-    s += (dbg && (atoi(dbg) & 32)) ? "constexpr bool STAMPS = true;\n" : "constexpr bool STAMPS = false;\n";
+    s += (debug_env().ablate & 32) ? "constexpr bool STAMPS = true;\n" : "constexpr bool STAMPS = false;\n";
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
@@ -1209,7 +1222,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         if (bpc * wpb > 16) bpc = std::max(1, 16 / wpb);
         const int grid = grid_for(p, n_tiles, wpb, bpc);
         size_t lds = (size_t)wpb * g.lds_per_wave;
-        if (const char* pad = getenv("MOLANN_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad); // diagnostic: lower the occupancy
+        lds += (size_t)debug_env().lds_pad; // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
         if (mode == 0 && p->jit_fn && (a.ablate & ~32) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
@@ -1224,7 +1237,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
                      p->jit_nl, grid, 64 * wpb, lds);
             return (int)le;
         }
-        const bool regs = p->regs_mode && !getenv("MOLANN_DEBUG_NO_REGS");
+        const bool regs = p->regs_mode;
 #define LAUNCH_LANE(W, M)                                                                                         \
     hipLaunchKernelGGL((frames_lane_kernel<W, M>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
                        p->d_ref64, (M == 2 ? p->d_items_slot : p->d_items), p->d_slots, p->d_wlane, a)
@@ -1246,7 +1259,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         // blocks per CU: all wave slots normally; on the unfused path leave registers and wave slots for the
         // MLP kernel that runs beside this one on the plan's side stream (MOLANN_WAVE_BPC to experiment)
         int bpc = (p->work_frames > 0 && mode == 0) ? 2 : 8;
-        if (const char* ev = getenv("MOLANN_WAVE_BPC")) bpc = std::max(1, atoi(ev));
+        if (debug_env().wave_bpc > 0) bpc = debug_env().wave_bpc;
         const int grid = grid_for(p, n_frames, wpb, bpc);
         hipLaunchKernelGGL(frames_wave_kernel, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref,
                            p->d_ref64, p->d_items, a);
@@ -1390,7 +1403,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     for (auto& it : items_slot)
         for (int i = 0; i < 4; ++i) it.idx[i] = slot(it.idx[i]);
     p->n_slots = (int)slots.size();
-    p->regs_mode = p->n_items > 0 && p->n_items <= 64 && p->n_slots <= 16 && align_is_prefix;
+    // (plan creation is setup time: MOLANN_DEBUG_NO_REGS / MOLANN_NO_JIT select the other generic modes here)
+    p->regs_mode = p->n_items > 0 && p->n_items <= 64 && p->n_slots <= 16 && align_is_prefix &&
+                   getenv("MOLANN_DEBUG_NO_REGS") == nullptr;
     memset(p->geom, 0, sizeof(p->geom));
     const bool lane_tables_fit = d->n_align <= 64 && (long)d->n_inp * 768 <= 65536;
     if (p->n_items > 0 && lane_tables_fit && cols_needed <= LANE_MAX_COLS)
