@@ -1727,7 +1727,7 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
     if (p->n_layers > 0 && !p->fused_mlp) return MOLANN_E_UNSUPPORTED; // wide MLPs: not yet
     if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
     molann_plan::LaneGeom g;
-    lane_geometry(g, 64 * p->n_inp * 12, 1);
+    lane_geometry(g, std::max(64 * p->n_inp * 12, 64 * 68 * 4), 1); // frame tile, reused as the [unit][frame] scratch
     if (!g.ok) return MOLANN_E_UNSUPPORTED;
     if (p->bwd_state == 0) {
         std::vector<char> code;
@@ -1809,7 +1809,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
             off = (off + 3) & ~3l;
         }
         molann_plan::LaneGeom gb;
-        lane_geometry(gb, 64 * d->n_inp * 12, 1);
+        lane_geometry(gb, std::max(64 * d->n_inp * 12, 64 * 68 * 4), 1);
         b.j.wpb = gb.wpb;
         src = jit_source_bwd(b, gb.lds_per_wave);
     }
