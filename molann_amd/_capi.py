@@ -46,11 +46,11 @@ class PlanDesc(ctypes.Structure):
 
 
 def build_library(force=False):
-    """Compile csrc/ for gfx950 with hipcc (seconds).  Used by __graft_entry__.build()."""
-    if force or not os.path.exists(LIB_PATH) or any(
-            os.path.getmtime(os.path.join(_CSRC, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("molann_kernels.hip", "molann_math.h", "molann_lane_jit.inc", "molann_lane_bwd.inc")) or os.path.getmtime(HEADER_PATH) > os.path.getmtime(LIB_PATH):
-        subprocess.check_call(["make", "-C", _CSRC, "libmolann_hip.so"])
+    """Compile csrc/: libmolann_hip.so (hipcc, gfx950, seconds) and libmolann_torch.so (g++, the TorchScript
+    operators over the same ABI).  make decides what is stale.  Used by __graft_entry__.build()."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "all"])
     return LIB_PATH
 
 

@@ -259,6 +259,12 @@ class AlignmentLayer(_PlanOwner, torch.nn.Module):
         print('local indices\n', self._local_align_atom_indices)
         print('\ncoordinates of reference state used in aligment:\n', self.ref_x.cpu().numpy())
 
+    def __prepare_scriptable__(self):
+        """`torch.jit.script(align)` (`test/test_molann.py:46`) compiles this instead, see molann_amd/script.py."""
+        from . import script
+        return script.ScriptPlan(script.make_desc(script.KIND_ALIGN, self.input_atom_num,
+                                                  align_idx=self._local_align_atom_indices), ref_x=self.ref_x)
+
     def _entry(self, x):
         entry = _get_entry(self, x, "align", lambda: _capi.Plan(
             self.input_atom_num, align_idx=self._local_align_atom_indices, ref_x=self.ref_x))
@@ -314,6 +320,9 @@ class FeatureMap(_PlanOwner, torch.nn.Module):
         _check_input(x, self.input_atom_num)
         return _run_features(self, x, None)
 
+    def __prepare_scriptable__(self):
+        return _script_features(self, None)
+
 
 class FeatureLayer(_PlanOwner, torch.nn.Module):
     """All features of a list, concatenated column-wise in list order (`ann.py:454-474`)."""
@@ -337,6 +346,21 @@ class FeatureLayer(_PlanOwner, torch.nn.Module):
     def forward(self, x):
         _check_input(x, self.input_atom_num)
         return _run_features(self, x, None)
+
+    def __prepare_scriptable__(self):
+        return _script_features(self, None)
+
+
+def _script_features(feature_owner, align_layer):
+    """The ScriptPlan of a FeatureMap / FeatureLayer, optionally behind an AlignmentLayer."""
+    from . import script
+    spec, uav = _feature_spec(feature_owner)
+    if align_layer is None:
+        return script.ScriptPlan(script.make_desc(script.KIND_FEATURES, feature_owner.input_atom_num, features=spec,
+                                                  use_angle_value=uav))
+    return script.ScriptPlan(script.make_desc(script.KIND_FEATURES, feature_owner.input_atom_num,
+                                              align_idx=align_layer._local_align_atom_indices, features=spec,
+                                              use_angle_value=uav), ref_x=align_layer.ref_x)
 
 
 def _run_features(feature_owner, x, align_layer, plan_owner=None):
@@ -392,6 +416,12 @@ class PreprocessingANN(_PlanOwner, torch.nn.Module):
         _check_input(x, self.feature_layer.input_atom_num)
         return _run_features(self.feature_layer, x, al, plan_owner=self)
 
+    def __prepare_scriptable__(self):
+        if not self._fusable():
+            return torch.nn.Sequential(self.align_layer, self.feature_layer)
+        al = self.align_layer if isinstance(self.align_layer, AlignmentLayer) else None
+        return _script_features(self.feature_layer, al)
+
 
 class MolANN(_PlanOwner, torch.nn.Module):
     """``ann_layers(preprocessing_layer(x))`` (`ann.py:606-624`).
@@ -411,6 +441,26 @@ class MolANN(_PlanOwner, torch.nn.Module):
 
     def get_preprocessing_layer(self):
         return self.preprocessing_layer
+
+    def __prepare_scriptable__(self):
+        """`torch.jit.script(molann).save(...)` (`test/test_molann.py:114`, `README.rst:49`): the fused plan as
+        one operator call when ann_layers is recognised, else the scripted preprocessing followed by ann_layers."""
+        from . import script
+        pp = self.preprocessing_layer
+        rec = recognise_mlp(self.ann_layers)
+        if rec is None or not (isinstance(pp, PreprocessingANN) and pp._fusable()):
+            return torch.nn.Sequential(pp, self.ann_layers)
+        linears, act = rec
+        al = pp.align_layer if isinstance(pp.align_layer, AlignmentLayer) else None
+        spec, uav = _feature_spec(pp.feature_layer)
+        dims = [linears[0].in_features] + [lin.out_features for lin in linears]
+        assert dims[0] == pp.feature_layer.output_dimension(), \
+            'ann_layers expects %d inputs but the feature layer produces %d' % (dims[0], pp.feature_layer.output_dimension())
+        desc = script.make_desc(script.KIND_FORWARD, pp.feature_layer.input_atom_num,
+                                align_idx=al._local_align_atom_indices if al is not None else None, features=spec,
+                                use_angle_value=uav, layer_dims=dims, activation=act,
+                                mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
+        return script.ScriptPlan(desc, ref_x=al.ref_x if al is not None else None, linears=linears)
 
     def _fast_state(self, x):
         """Everything about this model that does not change from call to call (which modules it is made

@@ -1,0 +1,328 @@
+// molann_torch.cpp - the plans of libmolann_hip.so as TorchScript operators.
+//
+// The reference's own tests end every case with torch.jit.script(module).save(...) (test/test_molann.py:36,
+// 46,62,75,101,114) and README.rst:49 ships models to MD engines that way.  A scripted module cannot call
+// ctypes, so the same C ABI (include/molann_hip.h) is bound here a second time, as dispatcher operators a
+// TorchScript graph can name:
+//
+//     molann::run(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor
+//     molann::run_backward(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases,
+//                          Tensor grad_out, bool need_x, bool need_params) -> Tensor[]
+//
+// `desc` is everything the modules fix at construction time, as integers (layout below; written by
+// molann_amd/script.py).  Plans are created on first use and cached per (desc, device).  The live tensors
+// (ref_x buffer, Linear parameters) are re-read whenever their storage or version counter changes, as in
+// molann_amd/ann.py.  Only the HIP dispatch key is registered: a CPU tensor raises, there is no fallback.
+// A libtorch host loads this library (dlopen / torch.ops.load_library) before torch::jit::load.
+//
+// desc: [0]=1 (layout version) [1]=kind (0 align, 1 features, 2 features+MLP) [2]=n_inp [3]=n_align
+//       [4]=n_features [5]=use_angle_value [6]=n_layers [7]=activation [8]=mlp_precision, then
+//       align_idx[n_align], feat_type[n_features], feat_ptr[n_features+1], feat_idx[feat_ptr[n_features]],
+//       layer_dims[n_layers+1] (only when n_layers > 0)
+
+#include <torch/library.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "molann_hip.h"
+
+namespace {
+
+enum { KIND_ALIGN = 0, KIND_FEATURES = 1, KIND_FORWARD = 2, DESC_HEAD = 9 };
+
+struct TensorKey {
+    const void* ptr = nullptr;
+    uint32_t version = 0;
+    bool operator!=(const TensorKey& o) const { return ptr != o.ptr || version != o.version; }
+};
+
+TensorKey key_of(const at::Tensor& t) { return {t.data_ptr(), t._version()}; }
+
+struct Entry {
+    molann_plan* plan = nullptr;
+    int kind = 0, n_inp = 0, n_align = 0, n_layers = 0, out_dim = 0, feature_dim = 0;
+    TensorKey ref_key;
+    std::vector<TensorKey> mlp_key;
+    std::mutex mu; // update_* + launch of one plan are one critical section
+    ~Entry() {
+        if (plan) molann_plan_destroy(plan);
+    }
+};
+
+void check(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, what, " failed: ", molann_error_string(rc), " (", rc, ")");
+}
+
+struct Parsed {
+    std::vector<int32_t> align_idx, feat_type, feat_ptr, feat_idx, layer_dims;
+    molann_plan_desc d;
+};
+
+// the integer list -> molann_plan_desc (pointers into `p`)
+void parse_desc(const std::vector<int64_t>& v, Parsed& p) {
+    TORCH_CHECK(v.size() >= DESC_HEAD && v[0] == 1, "molann::run: unknown descriptor layout");
+    const int64_t n_align = v[3], n_feat = v[4], n_layers = v[6];
+    TORCH_CHECK(n_align >= 0 && n_feat >= 0 && n_layers >= 0 && n_layers <= MOLANN_MAX_LAYERS, "molann::run: bad descriptor counts");
+    size_t pos = DESC_HEAD;
+    auto take = [&](std::vector<int32_t>& out, int64_t n) {
+        TORCH_CHECK(pos + (size_t)n <= v.size(), "molann::run: descriptor too short");
+        out.assign(v.begin() + pos, v.begin() + pos + n);
+        pos += (size_t)n;
+    };
+    take(p.align_idx, n_align);
+    take(p.feat_type, n_feat);
+    take(p.feat_ptr, n_feat > 0 ? n_feat + 1 : 0);
+    take(p.feat_idx, n_feat > 0 ? p.feat_ptr.back() : 0);
+    take(p.layer_dims, n_layers > 0 ? n_layers + 1 : 0);
+    TORCH_CHECK(pos == v.size(), "molann::run: descriptor has trailing entries");
+    molann_plan_desc& d = p.d;
+    d = molann_plan_desc();
+    d.abi_version = MOLANN_ABI_VERSION;
+    d.n_inp = (int32_t)v[2];
+    d.n_align = (int32_t)n_align;
+    d.align_idx = p.align_idx.data();
+    d.n_features = (int32_t)n_feat;
+    d.feat_type = p.feat_type.data();
+    d.feat_ptr = p.feat_ptr.data();
+    d.feat_idx = p.feat_idx.data();
+    d.use_angle_value = (int32_t)v[5];
+    d.n_layers = (int32_t)n_layers;
+    d.layer_dims = p.layer_dims.data();
+    d.activation = (int32_t)v[7];
+    d.mlp_precision = (int32_t)v[8];
+}
+
+std::mutex g_cache_mu;
+std::map<std::pair<std::vector<int64_t>, int>, std::shared_ptr<Entry>> g_cache;
+
+// plan for (desc, device of x); created with the current contents of ref_x
+std::shared_ptr<Entry> entry_for(const std::vector<int64_t>& desc, const at::Tensor& x, const at::Tensor& ref_x) {
+    const auto key = std::make_pair(desc, (int)x.get_device());
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return it->second;
+    Parsed p;
+    parse_desc(desc, p);
+    at::Tensor ref_host;
+    if (p.d.n_align > 0) {
+        TORCH_CHECK(ref_x.numel() == 3 * (int64_t)p.d.n_align, "molann::run: ref_x must be [n_align, 3]");
+        ref_host = ref_x.detach().to(at::kCPU, at::kFloat).contiguous();
+        p.d.ref_x = ref_host.data_ptr<float>();
+    }
+    auto e = std::make_shared<Entry>();
+    check(molann_plan_create(&p.d, &e->plan), "molann_plan_create");
+    e->kind = (int)desc[1];
+    e->n_inp = p.d.n_inp;
+    e->n_align = p.d.n_align;
+    e->n_layers = p.d.n_layers;
+    e->out_dim = molann_plan_out_dim(e->plan);
+    e->feature_dim = molann_plan_feature_dim(e->plan);
+    g_cache.emplace(key, e);
+    return e;
+}
+
+// AlignmentLayer on its own has no backward kernel; the same map written as alignment + one position item
+// per atom does (molann_amd/ann.py does the same)
+std::vector<int64_t> align_as_features(const std::vector<int64_t>& desc) {
+    const int64_t n_inp = desc[2], n_align = desc[3];
+    std::vector<int64_t> v(desc.begin(), desc.begin() + DESC_HEAD + n_align);
+    v[1] = KIND_FEATURES;
+    v[4] = 1; // one position feature over all atoms
+    v.push_back(MOLANN_FEAT_POSITION);
+    v.push_back(0);
+    v.push_back(n_inp);
+    for (int64_t i = 0; i < n_inp; ++i) v.push_back(i);
+    return v;
+}
+
+at::Tensor device_f32(const at::Tensor& t, const at::Tensor& like, const char* name) {
+    TORCH_CHECK(t.scalar_type() == at::kFloat, "molann::run: ", name, " must be float32, got ", t.scalar_type());
+    TORCH_CHECK(t.device() == like.device(), "molann::run: ", name, " is on ", t.device(), " but x is on ", like.device());
+    return t.contiguous();
+}
+
+// bring the plan's copies of the live tensors up to date (caller holds e.mu, device guard set)
+void sync_live(Entry& e, const at::Tensor& x, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
+               const std::vector<at::Tensor>& biases, hipStream_t stream) {
+    if (e.n_align > 0) {
+        const at::Tensor r = device_f32(ref_x.detach(), x, "ref_x");
+        const TensorKey k = key_of(ref_x);
+        if (k != e.ref_key) {
+            check(molann_plan_update_ref(e.plan, r.data_ptr<float>(), stream), "molann_plan_update_ref");
+            e.ref_key = k;
+        }
+    }
+    if (e.kind == KIND_FORWARD) {
+        TORCH_CHECK((int)weights.size() == e.n_layers && (int)biases.size() == e.n_layers,
+                    "molann::run: expected ", e.n_layers, " weight and bias tensors");
+        std::vector<TensorKey> k;
+        for (int l = 0; l < e.n_layers; ++l) { k.push_back(key_of(weights[l])); k.push_back(key_of(biases[l])); }
+        bool changed = k.size() != e.mlp_key.size();
+        for (size_t i = 0; !changed && i < k.size(); ++i) changed = k[i] != e.mlp_key[i];
+        if (changed) {
+            std::vector<at::Tensor> hold;
+            std::vector<const float*> W, B;
+            for (int l = 0; l < e.n_layers; ++l) {
+                hold.push_back(device_f32(weights[l].detach(), x, "weight"));
+                W.push_back(hold.back().data_ptr<float>());
+                hold.push_back(device_f32(biases[l].detach(), x, "bias"));
+                B.push_back(hold.back().data_ptr<float>());
+            }
+            check(molann_plan_update_mlp(e.plan, W.data(), B.data(), stream), "molann_plan_update_mlp");
+            e.mlp_key = k;
+        }
+    }
+}
+
+void check_x(const at::Tensor& x, const std::vector<int64_t>& desc) {
+    TORCH_CHECK(desc.size() >= DESC_HEAD, "molann::run: bad descriptor");
+    TORCH_CHECK(x.dim() == 3 && x.size(1) == desc[2] && x.size(2) == 3, "Input should be a 3d torch tensor, with sizes [*, ",
+                desc[2], ", 3]. Actual sizes: ", x.sizes());
+    TORCH_CHECK(x.scalar_type() == at::kFloat, "molann_amd kernels are float32; got ", x.scalar_type());
+}
+
+at::Tensor run_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                   std::vector<at::Tensor> biases) {
+    check_x(x_in, desc);
+    const at::Tensor x = x_in.contiguous();
+    const c10::DeviceGuard guard(x.device());
+    auto e = entry_for(desc, x, ref_x);
+    const int64_t n = x.size(0);
+    at::Tensor out = e->kind == KIND_ALIGN ? at::empty_like(x)
+                                           : at::empty({n, e->kind == KIND_FORWARD ? e->out_dim : e->feature_dim}, x.options());
+    if (n == 0) return out;
+    hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    sync_live(*e, x, ref_x, weights, biases, stream);
+    const float* xp = x.data_ptr<float>();
+    float* op = out.data_ptr<float>();
+    if (e->kind == KIND_ALIGN) check(molann_align_f32(e->plan, xp, n, op, stream), "molann_align_f32");
+    else if (e->kind == KIND_FEATURES) check(molann_features_f32(e->plan, xp, n, op, stream), "molann_features_f32");
+    else check(molann_forward_packed_f32(e->plan, xp, n, op, stream), "molann_forward_packed_f32");
+    return out;
+}
+
+// [grad_x or empty, flat parameter gradients (dW_l, db_l per layer) or empty]
+std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x,
+                                         std::vector<at::Tensor> weights, std::vector<at::Tensor> biases,
+                                         const at::Tensor& grad_out, bool need_x, bool need_params) {
+    check_x(x_in, desc);
+    const at::Tensor x = x_in.contiguous();
+    const c10::DeviceGuard guard(x.device());
+    const bool align_only = desc[1] == KIND_ALIGN;
+    auto e = entry_for(align_only ? align_as_features(desc) : desc, x, ref_x);
+    TORCH_CHECK(molann_plan_supports_backward(e->plan) == 1,
+                "no backward kernel for this plan (wide MLP / large frames / this activation): run it under torch.no_grad()");
+    const int64_t n = x.size(0);
+    const int64_t cols = e->kind == KIND_FORWARD ? e->out_dim : e->feature_dim;
+    at::Tensor g = grad_out.to(at::kFloat).reshape({n, cols}).contiguous();
+    at::Tensor gx = need_x ? at::empty_like(x) : at::empty({0}, x.options());
+    at::Tensor gp = need_params ? at::zeros({molann_plan_grad_params_size(e->plan)}, x.options()) : at::empty({0}, x.options());
+    if (n == 0) {
+        if (need_x) gx.zero_();
+        return {gx, gp};
+    }
+    hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    sync_live(*e, x, ref_x, weights, biases, stream);
+    check(molann_backward_f32(e->plan, x.data_ptr<float>(), g.data_ptr<float>(), n, need_x ? gx.data_ptr<float>() : nullptr,
+                              need_params ? gp.data_ptr<float>() : nullptr, stream),
+          "molann_backward_f32");
+    return {gx, gp};
+}
+
+at::Tensor call_run(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                    const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("molann::run", "")
+                         .typed<at::Tensor(const at::Tensor&, std::vector<int64_t>, const at::Tensor&, std::vector<at::Tensor>,
+                                           std::vector<at::Tensor>)>();
+    return op.call(x, desc, ref_x, weights, biases);
+}
+
+std::vector<at::Tensor> call_run_backward(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                                          const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases,
+                                          const at::Tensor& grad_out, bool need_x, bool need_params) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("molann::run_backward", "")
+                         .typed<std::vector<at::Tensor>(const at::Tensor&, std::vector<int64_t>, const at::Tensor&,
+                                                        std::vector<at::Tensor>, std::vector<at::Tensor>, const at::Tensor&, bool, bool)>();
+    return op.call(x, desc, ref_x, weights, biases, grad_out, need_x, need_params);
+}
+
+// forward = one launch of the plan, nothing but the inputs saved; backward = molann_backward_f32, which
+// recomputes the forward per frame (first-order only: the backward is not itself differentiable)
+struct RunFunction : public torch::autograd::Function<RunFunction> {
+    // apply() records one graph edge per at::Tensor / at::TensorList element and none for `desc`
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, std::vector<int64_t> desc,
+                              const at::Tensor& ref_x, at::TensorList weights, at::TensorList biases) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        at::Tensor out = call_run(x, desc, ref_x, weights.vec(), biases.vec());
+        std::vector<at::Tensor> saved = {x, ref_x};
+        for (auto& w : weights) saved.push_back(w);
+        for (auto& b : biases) saved.push_back(b);
+        ctx->save_for_backward(saved);
+        ctx->saved_data["desc"] = desc;
+        ctx->saved_data["n_layers"] = (int64_t)weights.size();
+        return out;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        const std::vector<int64_t> desc = ctx->saved_data["desc"].toIntVector();
+        const int64_t nl = ctx->saved_data["n_layers"].toInt();
+        const at::Tensor& x = saved[0];
+        const at::Tensor& ref_x = saved[1];
+        std::vector<at::Tensor> weights(saved.begin() + 2, saved.begin() + 2 + nl), biases(saved.begin() + 2 + nl, saved.begin() + 2 + 2 * nl);
+        // graph edges (tensors only): x, ref_x, weights..., biases...; returned list (all inputs): x, desc, ref_x, ...
+        const bool need_x = ctx->needs_input_grad(0);
+        bool need_p = false;
+        for (int64_t i = 0; i < 2 * nl; ++i) need_p = need_p || ctx->needs_input_grad(2 + i);
+        std::vector<at::Tensor> g;
+        {
+            at::AutoDispatchBelowADInplaceOrView below;
+            g = call_run_backward(x, desc, ref_x, weights, biases, grad_outputs[0], need_x, need_p);
+        }
+        torch::autograd::variable_list out(3 + 2 * nl);
+        if (need_x) out[0] = g[0];
+        if (need_p) {
+            int64_t off = 0;
+            for (int64_t l = 0; l < nl; ++l) { // flat layout: dW_l[J][K] then db_l[J], layer after layer
+                const int64_t nw = weights[l].numel(), nb = biases[l].numel();
+                if (ctx->needs_input_grad(2 + l)) out[3 + l] = g[1].narrow(0, off, nw).view(weights[l].sizes());
+                if (ctx->needs_input_grad(2 + nl + l)) out[3 + nl + l] = g[1].narrow(0, off + nw, nb).view(biases[l].sizes());
+                off += nw + nb;
+            }
+        }
+        return out;
+    }
+};
+
+at::Tensor run_autograd(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                        std::vector<at::Tensor> biases) {
+    return RunFunction::apply(x, desc, ref_x, at::TensorList(weights), at::TensorList(biases));
+}
+
+} // namespace
+
+TORCH_LIBRARY(molann, m) {
+    m.def("run(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor");
+    m.def("run_backward(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, bool need_x, "
+          "bool need_params) -> Tensor[]");
+}
+
+TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP device "cuda"
+    m.impl("run", run_hip);
+    m.impl("run_backward", run_backward_hip);
+}
+
+TORCH_LIBRARY_IMPL(molann, Autograd, m) { m.impl("run", run_autograd); }
