@@ -854,6 +854,81 @@ __global__ void pack_mfma_kernel(void* __restrict__ dst_v, PackArgs p) {
     }
 }
 
+
+// ---- chain MLP (molann_mlp_jit.inc): host mirror of the kernel text's constexpr geometry --------------------
+struct ChainGeom {
+    int nl;
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int ub(int l) const { return (dims[l + 1] + 15) / 16; }
+    int ubp(int l) const { return (ub(l) + 1) & ~1; }
+    int ks(int l) const { return l == 0 ? (dims[0] + 31) / 32 : ubp(l - 1) / 2; }
+    int npair() const { return (nl + 1) / 2; }
+    bool has_c(int p) const { return 2 * p + 1 < nl; }
+    int nchunk(int p) const { return ubp(2 * p) / 2; }
+    int slab_frags(int p) const { return 2 * ks(2 * p) + (has_c(p) ? ub(2 * p + 1) : 0); }
+    int slab_max() const { int m = 0; for (int p = 0; p < npair(); ++p) m = std::max(m, slab_frags(p)); return m; }
+    long total_frags() const { long s = 0; for (int p = 0; p < npair(); ++p) s += (long)nchunk(p) * slab_frags(p); return s; }
+    int bias_off(int l) const { int s = 0; for (int i = 0; i < l; ++i) s += 16 * ubp(i); return s; }
+    // registers (VGPR + AGPR) the kernel keeps live per 16-frame block: the pair's input operands, the C
+    // layer's accumulators, the P chunk, and half of the next pair's operands while they are being formed
+    int regs_per_fb() const {
+        int m = 0;
+        for (int p = 0; p < npair(); ++p) {
+            const int ksin = ks(2 * p), ubc = has_c(p) ? ub(2 * p + 1) : 0, ksn = has_c(p) ? ubp(2 * p + 1) / 2 : 0;
+            m = std::max(m, 4 * (ksin + ubc + 2 + (ksn + 1) / 2));
+        }
+        return m;
+    }
+};
+
+struct ChainPackArgs {
+    const float* W[MOLANN_MAX_LAYERS];
+    const float* b[MOLANN_MAX_LAYERS];
+    int dims[MOLANN_MAX_LAYERS + 1];
+    int n_layers, npair;
+    int pair_start[MOLANN_MAX_LAYERS / 2 + 1]; // first fragment of pair p (last entry: total)
+    int slab_frags[MOLANN_MAX_LAYERS / 2];
+    int ks_in[MOLANN_MAX_LAYERS / 2];
+    int bias_off[MOLANN_MAX_LAYERS + 1];
+    long stream_bytes;
+};
+
+// Fragment F of the stream = 64 lanes x 16 B: lane (i = l&15, q = l>>4) holds A[j = 16 ub + i][k slot s = 0..7];
+// layer 0: k = 32 ks + 8q + s (the order of the feature row), later layers: k = 16(2ks + (s>>2)) + 4q + (s&3)
+// (the order the previous layer's accumulators come in).  Order of fragments: see molann_mlp_jit.inc.
+__global__ void pack_chain_kernel(unsigned char* __restrict__ dst, ChainPackArgs a) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    const long total = (long)a.pair_start[a.npair] * 64;
+    for (long e = tid; e < total; e += nthreads) {
+        const int F = (int)(e >> 6), lane = (int)(e & 63), i = lane & 15, q = lane >> 4;
+        int p = 0;
+        while (p + 1 < a.npair && F >= a.pair_start[p + 1]) ++p;
+        const int rel = F - a.pair_start[p], c = rel / a.slab_frags[p], f = rel % a.slab_frags[p];
+        int l, ub, ks;
+        if (f < 2 * a.ks_in[p]) { l = 2 * p; ks = f >> 1; ub = 2 * c + (f & 1); }
+        else { l = 2 * p + 1; ub = f - 2 * a.ks_in[p]; ks = c; }
+        const int K = a.dims[l], J = a.dims[l + 1], j = 16 * ub + i;
+        unsigned short v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = l == 0 ? 32 * ks + 8 * q + s : 16 * (2 * ks + (s >> 2)) + 4 * q + (s & 3);
+            v[s] = f2bf((j < J && k < K) ? a.W[l][(long)j * K + k] : 0.f);
+        }
+        uint4 w;
+        w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
+        w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+        *(uint4*)(dst + (size_t)F * 1024 + lane * 16) = w;
+    }
+    float* bias = (float*)(dst + a.stream_bytes);
+    for (long e = tid; e < a.bias_off[a.n_layers]; e += nthreads) {
+        int l = 0;
+        while (l + 1 < a.n_layers && e >= a.bias_off[l + 1]) ++l;
+        const int u = (int)e - a.bias_off[l];
+        bias[e] = u < a.dims[l + 1] ? a.b[l][u] : 0.f;
+    }
+}
+
 // ref_x (device, centred) -> plan copy + the constants the kernels need after it
 __global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ dst64, const float* __restrict__ ref,
                                 int n_align) {
@@ -944,6 +1019,14 @@ struct molann_plan {
     hipFunction_t bwd_fn;      // backward kernel, compiled at the first molann_backward_f32
     int bwd_state;             // 0 not tried, 1 ready, -1 unavailable
     int n_grad_params;         // floats of the parameter-gradient buffer (dW_l[J][K], db_l[J] per layer)
+    // plan-specialised wide bf16 MLP (molann_mlp_jit.inc); nullptr -> mlp_mfma_kernel<bf16>
+    hipModule_t chain_mod;
+    hipFunction_t chain_fn;
+    unsigned char* d_wchain;   // weight fragments in consumption order, then the padded fp32 biases
+    long chain_stream_bytes;
+    int chain_fb;              // 16-frame blocks per wave
+    char chain_note[96];
+    char mlp_info[96];         // name + geometry of the last MLP kernel launch
     int n_slots;
     bool regs_mode;
     int* d_slots;
@@ -1111,6 +1194,20 @@ std::string jit_source(const JitSpec& j) {
     return s;
 }
 
+// wide bf16 MLP: layer widths, activation and frames per wave as constants
+std::string jit_source_chain(const ChainGeom& g, int act, int fb) {
+    std::string s = "// preamble generated from the plan\n";
+    char t[64];
+    snprintf(t, sizeof(t), "constexpr int NL = %d;\n", g.nl); s += t;
+    s += "constexpr int DIMS[] = {";
+    for (int i = 0; i <= g.nl; ++i) { snprintf(t, sizeof(t), "%s%d", i ? ", " : "", g.dims[i]); s += t; }
+    s += "};\n";
+    snprintf(t, sizeof(t), "constexpr int ACT = %d;\nconstexpr int FB = %d;\n", act, fb); s += t;
+    s += "#line 1 \"molann_mlp_jit.inc\"\n";
+    s += join_chunks(k_src_molann_mlp_jit_inc);
+    return s;
+}
+
 // backward kernel: the forward preamble + where the weights live (fp32 MFMA copy: Wp[Jp][Kp], bias[Jp]) and
 // the layout of the parameter-gradient buffer (torch layout: dW[J][K] then db[J], layer after layer)
 std::string jit_source_bwd(const JitSpecBox& b, int lds_per_wave) {
@@ -1256,9 +1353,10 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
                  mode == 1 ? "align_out" : (regs ? "features_regs" : "features_lds"), grid, 64 * wpb, lds);
     } else {
         const int wpb = 4;
-        // blocks per CU: all wave slots normally; on the unfused path leave registers and wave slots for the
-        // MLP kernel that runs beside this one on the plan's side stream (MOLANN_WAVE_BPC to experiment)
-        int bpc = (p->work_frames > 0 && mode == 0) ? 2 : 8;
+        // blocks per CU: all wave slots.  (The gather is HBM-latency bound and wants every wave it can get; the MLP
+        // kernel on the plan's side stream takes the CUs it needs as gather blocks retire.  Measured, 262144
+        // frames: C5 5.8e7 / 6.8e7 / 7.3e7 frames/s at 2 / 4 / 8 blocks per CU.  MOLANN_WAVE_BPC to experiment.)
+        int bpc = 8;
         if (debug_env().wave_bpc > 0) bpc = debug_env().wave_bpc;
         const int grid = grid_for(p, n_frames, wpb, bpc);
         hipLaunchKernelGGL(frames_wave_kernel, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref,
@@ -1269,6 +1367,16 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
 }
 
 int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, float* out, hipStream_t stream) {
+    if (p->chain_fn) { // plan-specialised chain kernel: one 4-wave block per CU, 64*FB frames per block and tile
+        const long tile = 64l * p->chain_fb, n_tiles = (n_frames + tile - 1) / tile;
+        const int grid = (int)std::min<long>(n_tiles, p->num_cus);
+        struct { const float* feat; float* out; const unsigned char* w; const float* b; long n; int in_stride; } ka =
+            {feat, out, p->d_wchain, (const float*)(p->d_wchain + p->chain_stream_bytes), n_frames, in_stride};
+        size_t ksz = sizeof(ka);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+        snprintf(p->mlp_info, sizeof(p->mlp_info), "molann_mlp_chain<bf16,FB=%d> (plan-specialised) grid=%d block=256", p->chain_fb, grid);
+        return (int)hipModuleLaunchKernel(p->chain_fn, grid, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg);
+    }
     MlpArgs a;
     memset(&a, 0, sizeof(a));
     a.n_frames = n_frames;
@@ -1294,6 +1402,8 @@ int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, 
     const long n_blocks = (n_frames + 15) / 16;
     const int grid = grid_for(p, n_blocks, wpb, bpc);
     const size_t lds = (size_t)wpb * p->mlp_lds_per_wave;
+    snprintf(p->mlp_info, sizeof(p->mlp_info), "mlp_mfma_kernel<%s> grid=%d block=%d lds=%zu", p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32",
+             grid, 64 * wpb, lds);
     if (p->mlp_prec == MOLANN_MLP_BF16)
         hipLaunchKernelGGL((mlp_mfma_kernel<true>), dim3(grid), dim3(64 * wpb), lds, stream, feat, out, p->d_wmfma, a);
     else
@@ -1466,6 +1576,24 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         }
     }
     const size_t o_wmfma = carve(std::max<size_t>(16, mfma_bytes));
+    // wide bf16 MLP next to a gather kernel: the chain kernel's weight stream (molann_mlp_jit.inc), when its
+    // two LDS slabs fit and at least one 16-frame block per wave fits the register file
+    ChainGeom cg;
+    memset(&cg, 0, sizeof(cg));
+    size_t chain_bytes = 0;
+    int chain_fb = 0;
+    if (bf16 && d->n_layers > 0 && !p->fused_mlp) {
+        cg.nl = d->n_layers;
+        for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = p->dims[i];
+        for (int fb = 4; fb >= 1 && chain_fb == 0; --fb) // upper bound; plan creation steps down while the build spills
+            if (fb * cg.regs_per_fb() <= 512) chain_fb = fb;
+        if (2 * cg.slab_max() * 1024 > 163840 - 1024) chain_fb = 0;
+        if (chain_fb > 0) {
+            p->chain_stream_bytes = cg.total_frags() * 1024;
+            chain_bytes = (size_t)p->chain_stream_bytes + (size_t)cg.bias_off(cg.nl) * 4;
+        }
+    }
+    const size_t o_wchain = carve(std::max<size_t>(16, chain_bytes));
     p->work_frames = 0;
     size_t work_bytes = 0;
     if (d->n_layers > 0 && d->n_features > 0 && !p->fused_mlp) {
@@ -1491,6 +1619,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_wlane = (float*)(p->blob + o_wlane);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
+    p->d_wchain = p->blob + o_wchain;
 
     // ---- upload (synchronous: plan creation is setup time) --------------------------------------
     if (d->n_align > 0) {
@@ -1566,6 +1695,31 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
         }
     }
+    // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
+    snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
+    if (chain_fb > 0 && !(nojit && nojit[0] == '1')) {
+        // most frames per wave (A-fragment reuse) that the register file holds without scratch
+        int rc = -1;
+        for (int fb = chain_fb; fb >= 1 && !p->chain_fn; --fb) {
+            std::vector<char> code;
+            std::string log;
+            rc = jit_compile(jit_source_chain(cg, p->act, fb), code, log);
+            hipModule_t mod = nullptr;
+            hipFunction_t fn = nullptr;
+            if (rc != 0 || hipModuleLoadData(&mod, code.data()) != hipSuccess ||
+                hipModuleGetFunction(&fn, mod, "molann_mlp_chain") != hipSuccess) {
+                if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann chain jit failed rc=%d\n%s\n", rc, log.c_str());
+                if (mod) (void)hipModuleUnload(mod);
+                break;
+            }
+            int scratch = 0;
+            (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
+            if (scratch > 0 && fb > 1) { (void)hipModuleUnload(mod); continue; }
+            p->chain_mod = mod; p->chain_fn = fn; p->chain_fb = fb;
+            snprintf(p->chain_note, sizeof(p->chain_note), "chain: specialised kernel, FB=%d, %zu bytes", fb, code.size());
+        }
+        if (!p->chain_fn) snprintf(p->chain_note, sizeof(p->chain_note), "chain: unavailable (rc=%d), mlp_mfma_kernel", rc);
+    }
     *out_plan = p;
     return MOLANN_OK;
 }
@@ -1574,6 +1728,7 @@ int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
     if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
+    if (p->chain_mod) (void)hipModuleUnload(p->chain_mod);
     delete p->spec;
     if (p->side) {
         (void)hipStreamSynchronize(p->side);
@@ -1620,6 +1775,24 @@ int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* c
         hipLaunchKernelGGL(pack_lane_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
     // the MFMA copy serves molann_mlp_packed_f32 and the unfused forward
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(64, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wmfma, a);
+    if (p->chain_fn) {
+        ChainGeom g;
+        memset(&g, 0, sizeof(g));
+        g.nl = p->n_layers;
+        for (int i = 0; i <= p->n_layers; ++i) g.dims[i] = p->dims[i];
+        ChainPackArgs c;
+        memset(&c, 0, sizeof(c));
+        c.n_layers = g.nl; c.npair = g.npair(); c.stream_bytes = p->chain_stream_bytes;
+        for (int i = 0; i <= g.nl; ++i) { c.dims[i] = g.dims[i]; c.bias_off[i] = g.bias_off(i); }
+        for (int l = 0; l < g.nl; ++l) { c.W[l] = W[l]; c.b[l] = b[l]; }
+        int start = 0;
+        for (int q = 0; q < c.npair; ++q) {
+            c.pair_start[q] = start; c.slab_frags[q] = g.slab_frags(q); c.ks_in[q] = g.ks(2 * q);
+            start += g.nchunk(q) * g.slab_frags(q);
+        }
+        c.pair_start[c.npair] = start;
+        hipLaunchKernelGGL(pack_chain_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, p->d_wchain, c);
+    }
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) p->mlp_packed = true;
     return (int)e;
@@ -1658,7 +1831,9 @@ int molann_mlp_packed_f32(const molann_plan* cp, const float* f, int64_t n, floa
     if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
     const int c = check_io(f, out, n);
     if (c != MOLANN_OK || n == 0) return c;
-    return launch_mlp(p, f, n, p->dims[0], out, (hipStream_t)stream);
+    const int e = launch_mlp(p, f, n, p->dims[0], out, (hipStream_t)stream);
+    snprintf(p->last_info, sizeof(p->last_info), "%s", p->mlp_info);
+    return e;
 }
 
 int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, float* out, molann_stream_t stream) {
@@ -1691,8 +1866,7 @@ int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, 
         HIP_TRY(hipEventRecord(p->ev_mlp[h], p->side));
     }
     for (int h = 0; h < 2 && h < i; ++h) HIP_TRY(hipStreamWaitEvent(main, p->ev_mlp[h], 0)); // join
-    snprintf(p->last_info, sizeof(p->last_info), "%.170s || mlp_mfma_kernel<%s> chunk=%ld", info,
-             p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->work_frames);
+    snprintf(p->last_info, sizeof(p->last_info), "%.130s || %.90s chunk=%ld", info, p->mlp_info, p->work_frames);
     return MOLANN_OK;
 }
 
@@ -1764,6 +1938,29 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
 int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int cap) {
     const int v = validate_desc(d);
     if (v != MOLANN_OK) return v;
+    if (do_compile & 4) { // the wide bf16 MLP kernel of the same plan (FB as plan creation would choose it)
+        if (d->n_layers <= 0) return MOLANN_E_STAGE;
+        ChainGeom cg;
+        memset(&cg, 0, sizeof(cg));
+        cg.nl = d->n_layers;
+        for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = d->layer_dims[i];
+        int fb = 0;
+        for (int f = 4; f >= 1 && fb == 0; --f)
+            if (f * cg.regs_per_fb() <= 400) fb = f;
+        if (fb == 0 || 2 * cg.slab_max() * 1024 > 163840 - 1024) return MOLANN_E_UNSUPPORTED;
+        const std::string csrc = jit_source_chain(cg, d->activation, fb);
+        if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", csrc.c_str());
+        if (do_compile & 1) {
+            std::vector<char> code;
+            std::string log;
+            const int rc = jit_compile(csrc, code, log);
+            if (rc != 0) {
+                if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", log.c_str());
+                return rc > 0 ? rc : MOLANN_E_UNSUPPORTED;
+            }
+        }
+        return (int)csrc.size();
+    }
     JitSpec j;
     std::vector<int> slot_of(d->n_inp, -1);
     auto slot = [&](int atom) {

@@ -41,7 +41,7 @@ enum { KIND_ALIGN = 0, KIND_FEATURES = 1, KIND_FORWARD = 2, DESC_HEAD = 9 };
 
 struct TensorKey {
     const void* ptr = nullptr;
-    uint32_t version = 0;
+    int64_t version = 0;
     bool operator!=(const TensorKey& o) const { return ptr != o.ptr || version != o.version; }
 };
 

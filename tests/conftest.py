@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built libraries (they are git-ignored): build them once, as
+    __graft_entry__.build() does.  Nothing is rebuilt when they are there (the GPU box receives them built)."""
+    from molann_amd import _capi, script
+    if not (os.path.exists(_capi.LIB_PATH) and os.path.exists(script.TORCH_LIB_PATH)):
+        _capi.build_library()
+
+
 @pytest.fixture(scope="session")
 def hip_device():
     import torch
