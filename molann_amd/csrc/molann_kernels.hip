@@ -574,6 +574,12 @@ __device__ __forceinline__ V3 load_atom(const float* __restrict__ xf, int k) {
     return v3(xf[3 * k], xf[3 * k + 1], xf[3 * k + 2]);
 }
 
+// PRE: rounds of 64 feature items whose records live in registers for the whole kernel and whose atoms are
+// loaded at the top of each frame, TOGETHER with the alignment atoms: one HBM round trip per frame instead of
+// two dependent ones, and a 128-B line that holds both kinds of atom is fetched while it is still in L2 (with
+// 16 waves x 60 KB per CU in flight, the alignment phase's lines are long evicted by the time a second phase
+// would ask for them again).  Items beyond 64 PRE take the two-phase loop.
+template <int PRE>
 __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           const int* __restrict__ align_idx,
                                                           const float* __restrict__ ref,
@@ -584,11 +590,32 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
     const int wpb = (int)(blockDim.x >> 6);
     const auto refc = as_const(ref);
     const bool has_align = a.n_align > 0;
+    constexpr int PR = PRE > 0 ? PRE : 1;
+    int pt[PR], pc[PR], pi[PR][4];
+    bool pon[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int it = lane + 64 * r;
+        pon[r] = PRE > 0 && a.mode != 1 && it < a.n_items;
+        pt[r] = 0; pc[r] = 0; pi[r][0] = pi[r][1] = pi[r][2] = pi[r][3] = 0;
+        if (pon[r]) {
+            const int4 d0 = ((const int4*)items)[2 * it];
+            const int2 d1 = ((const int2*)items)[4 * it + 2];
+            pt[r] = d0.x; pc[r] = d0.y; pi[r][0] = d0.z; pi[r][1] = d0.w; pi[r][2] = d1.x; pi[r][3] = d1.y;
+        }
+    }
 
     for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
         const float* xf = x + f * (long)a.frame_dw;
         float R[9];
         V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        V3 pa[PR][4]; // raw atoms of this lane's items (atom 0 for lanes without an item: a harmless L1 hit)
+        if constexpr (PRE > 0) {
+#pragma unroll
+            for (int r = 0; r < PR; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pa[r][j] = load_atom(xf, pi[r][j]);
+        }
         if (has_align) {
             const int k0 = as_const(align_idx)[0];
             c0 = load_atom(xf, k0);
@@ -633,8 +660,26 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
         }
 
         float* of = out + f * (long)a.out_cols;
+        if constexpr (PRE > 0) {
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                if (!pon[r]) continue;
+                V3 p0 = pa[r][0], p1 = pa[r][1], p2 = pa[r][2], p3 = pa[r][3];
+                if (has_align) {
+                    p0 = rotate((p0 - c0) - dl, R);
+                    p1 = rotate((p1 - c0) - dl, R);
+                    p2 = rotate((p2 - c0) - dl, R);
+                    p3 = rotate((p3 - c0) - dl, R);
+                }
+                float v[3];
+                const int w = eval_item(pt[r], p0, p1, p2, p3, v);
+                of[pc[r]] = v[0];
+                if (w > 1) of[pc[r] + 1] = v[1];
+                if (w > 2) of[pc[r] + 2] = v[2];
+            }
+        }
 #pragma unroll 2
-        for (int it = lane; it < a.n_items; it += 64) {
+        for (int it = lane + 64 * PRE; it < a.n_items; it += 64) {
             const int4 d0 = ((const int4*)items)[2 * it];
             const int2 d1 = ((const int2*)items)[4 * it + 2];
             const int type = d0.x, col = d0.y, i0 = d0.z, i1 = d0.w, i2 = d1.x, i3 = d1.y;
@@ -964,12 +1009,13 @@ inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // diagnostic switches, read once per process (never on the launch path)
 struct DebugEnv {
-    int ablate, lds_pad, wave_bpc;
+    int ablate, lds_pad, wave_bpc, wave_pre;
     DebugEnv() {
         const char* e;
         ablate = (e = getenv("MOLANN_DEBUG_ABLATE")) ? atoi(e) : 0;
         lds_pad = (e = getenv("MOLANN_DEBUG_LDS_PAD")) ? atoi(e) : 0;
         wave_bpc = (e = getenv("MOLANN_WAVE_BPC")) ? atoi(e) : 0;
+        wave_pre = (e = getenv("MOLANN_WAVE_PRE")) ? atoi(e) : -1; // item rounds preloaded by frames_wave_kernel
     }
 };
 const DebugEnv& debug_env() {
@@ -1359,9 +1405,21 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         int bpc = 8;
         if (debug_env().wave_bpc > 0) bpc = debug_env().wave_bpc;
         const int grid = grid_for(p, n_frames, wpb, bpc);
-        hipLaunchKernelGGL(frames_wave_kernel, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref,
-                           p->d_ref64, p->d_items, a);
-        snprintf(p->last_info, sizeof(p->last_info), "frames_wave_kernel grid=%d block=%d mode=%d", grid, 64 * wpb, mode);
+        // item rounds (64 items each) whose atoms are loaded with the alignment atoms.  Measured (PMC, C5, 256 items):
+        // 4 rounds: 519 TCC misses/frame, 279 us per 21 845 frames; two-phase: 603 misses/frame, 291 us.  With one
+        // round or less (C4) the extra registers cost more occupancy than the shared lines save: two-phase.
+        int pre = (mode == 1 || p->n_items <= 64) ? 0 : (p->n_items <= 128 ? 2 : 4);
+        if (debug_env().wave_pre >= 0) pre = debug_env().wave_pre;
+#define LAUNCH_WAVE(P)                                                                                                    \
+    hipLaunchKernelGGL(frames_wave_kernel<P>, dim3(grid), dim3(64 * wpb), 0, stream, x, out, p->d_align_idx, p->d_ref, \
+                       p->d_ref64, p->d_items, a)
+        if (pre >= 4) LAUNCH_WAVE(4);
+        else if (pre >= 2) LAUNCH_WAVE(2);
+        else if (pre == 1) LAUNCH_WAVE(1);
+        else LAUNCH_WAVE(0);
+#undef LAUNCH_WAVE
+        snprintf(p->last_info, sizeof(p->last_info), "frames_wave_kernel<pre=%d> grid=%d block=%d mode=%d", pre >= 4 ? 4 : (pre >= 2 ? 2 : pre),
+                 grid, 64 * wpb, mode);
     }
     return (int)hipGetLastError();
 }
