@@ -161,7 +161,7 @@ def main():
             all_gather_outputs(y)
         torch.cuda.synchronize()
 
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -171,10 +171,12 @@ def main():
         ev1.record()
         if distributed and not args.no_gather:
             y_all = all_gather_outputs(y)
+        ev2.record()
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration, launch stream
+        gather_ms = ev1.elapsed_time(ev2)                # the one all-gather (0 when there is none)
 
         # per-launch durations (outside the timed region) for the spread
         per = []
@@ -191,9 +193,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        kmax = torch.tensor([kernel_ms, gather_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        kernel_ms = float(kmax.item())
+        kernel_ms, gather_ms = float(kmax[0].item()), float(kmax[1].item())
 
     if rank == 0:
         total_frames = frames * world * args.steps
@@ -233,6 +235,13 @@ def main():
                          "dense_frac_of_measured_copy_bw": dense_bytes * frames / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                          "launch_ms_avg": kernel_ms, "launch_ms_min": per[0], "launch_ms_median": per[len(per) // 2]},
         }
+        if distributed:
+            # value (above) is the contract's number: K steps + the final all-gather + both barriers, max over ranks.
+            # The same run split into its two phases (HIP events, max over ranks), because one all-gather of
+            # 7 x [frames, d_out] per rank over xGMI costs as much as several 22-atom steps:
+            rec["phases"] = {"compute_ms_per_step": kernel_ms, "compute_frames_per_s": frames * world / (kernel_ms * 1e-3),
+                             "allgather_ms": gather_ms,
+                             "allgather_bytes_received_per_rank": (world - 1) * frames * int(y.shape[1]) * 4}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w, model, args.cpu_seconds)
             rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
