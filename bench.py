@@ -43,8 +43,8 @@ HBM_COPY_GBS = 6290.0       # measured float4 copy (same guide)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=wl.workload_names())
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
     ap.add_argument("--buffers", type=int, default=0, help="distinct input buffers to rotate over")
@@ -210,12 +210,8 @@ def main():
                 traffic = json.load(open(tfile)).get(w.name, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        plan_info = ""
-        try:
-            cache = model._plans()
-            plan_info = list(cache.values())[-1].plan.last_launch_info() if cache else ""
-        except Exception:
-            pass
+        from molann_amd.ann import last_launch_info
+        plan_info = last_launch_info(model)
         rec = {
             "metric": "frames/sec (MolANN forward, 22-atom ala-dipeptide)" if w.n_atoms == 22 else
                       "frames/sec (MolANN forward, %d-atom system)" % w.n_atoms,

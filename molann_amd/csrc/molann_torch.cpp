@@ -26,6 +26,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -104,9 +105,17 @@ void parse_desc(const std::vector<int64_t>& v, Parsed& p) {
 std::mutex g_cache_mu;
 std::map<std::pair<std::vector<int64_t>, int>, std::shared_ptr<Entry>> g_cache;
 
+// molann_plan_create reads two switches from the environment (MOLANN_NO_JIT, MOLANN_DEBUG_NO_REGS: which kernel
+// family serves the plan); a plan built under other settings must not be handed out, so they are part of the key
+int cache_device_key(int device) {
+    const char* a = getenv("MOLANN_NO_JIT");
+    const char* b = getenv("MOLANN_DEBUG_NO_REGS");
+    return device | ((a && a[0] == '1') ? 1 << 16 : 0) | ((b && b[0] == '1') ? 1 << 17 : 0);
+}
+
 // plan for (desc, device of x); created with the current contents of ref_x
 std::shared_ptr<Entry> entry_for(const std::vector<int64_t>& desc, const at::Tensor& x, const at::Tensor& ref_x) {
-    const auto key = std::make_pair(desc, (int)x.get_device());
+    const auto key = std::make_pair(desc, cache_device_key((int)x.get_device()));
     std::lock_guard<std::mutex> lock(g_cache_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) return it->second;
@@ -240,6 +249,22 @@ std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int
     return {gx, gp};
 }
 
+// name + geometry of the kernels the plan of (desc, device) launched last ("" before its first launch)
+std::string launch_info(std::vector<int64_t> desc, int64_t device) {
+    std::shared_ptr<Entry> e;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        auto it = g_cache.find(std::make_pair(desc, cache_device_key((int)device)));
+        if (it == g_cache.end()) return "";
+        e = it->second;
+    }
+    char buf[256];
+    buf[0] = 0;
+    std::lock_guard<std::mutex> lock(e->mu);
+    molann_plan_last_launch_info(e->plan, buf, (int)sizeof(buf));
+    return buf;
+}
+
 at::Tensor call_run(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
                     const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases) {
     static auto op = c10::Dispatcher::singleton()
@@ -318,6 +343,7 @@ TORCH_LIBRARY(molann, m) {
     m.def("run(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor");
     m.def("run_backward(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, bool need_x, "
           "bool need_params) -> Tensor[]");
+    m.def("launch_info(int[] desc, int device) -> str", launch_info);
 }
 
 TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP device "cuda"

@@ -8,6 +8,7 @@ import torch
 from build_util import build_modules, oracle_for_workload, workload_model
 from golden_util import Case, case_names
 from molann_amd import workloads as wl
+from molann_amd.ann import last_launch_info
 
 pytestmark = pytest.mark.gpu
 
@@ -254,7 +255,7 @@ def test_generic_lane_kernels(name, env, hip_device, monkeypatch):
     model = build_modules(c, hip_device)
     got = _run(model, c.x.to(hip_device))
     pp = model if c.kind == "features" else model.preprocessing_layer
-    info = list((model if c.kind != "features" else pp)._plans().values())[-1].plan.last_launch_info()
+    info = last_launch_info(model if c.kind != "features" else pp)
     assert "frames_lane_kernel" in info, info
     assert ("features_lds" in info) == ("MOLANN_DEBUG_NO_REGS" in env) or "features_regs" not in info
     assert float((got - c.out_f32).abs().max()) <= c.tolerance_vs_f32()
@@ -264,7 +265,7 @@ def test_specialised_kernel_is_used_by_default(hip_device):
     c = Case("molann_C3")
     model = build_modules(c, hip_device)
     _run(model, c.x.to(hip_device))
-    info = list(model._plans().values())[-1].plan.last_launch_info()
+    info = last_launch_info(model)
     assert "molann_lane_jit" in info, info
 
 

@@ -20,3 +20,19 @@ def timeit(fn, n=2000):
 print("eager  : %.2f us per 1024-frame forward" % timeit(lambda: model(x)))
 print("graph  : %.2f us per 1024-frame forward (replay incl. input copy)" % timeit(lambda: g(x)))
 print("replay : %.2f us (graph.replay only)" % timeit(lambda: g.graph.replay()))
+scripted = torch.jit.script(model)
+print("script : %.2f us per 1024-frame forward (TorchScript module -> molann::run)" % timeit(lambda: scripted(x)))
+x1 = x[:1].contiguous()
+print("eager  : %.2f us per 1-frame forward (the MD-engine call pattern)" % timeit(lambda: model(x1)))
+print("script : %.2f us per 1-frame forward" % timeit(lambda: scripted(x1)))
+xg = x1.clone().requires_grad_(True)
+def force():
+    y = scripted(xg)
+    return torch.autograd.grad(y.sum(), [xg])[0]
+def timeit_grad(fn, n=1000):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e6
+print("script : %.2f us per 1-frame forward + forces (autograd through molann::run_backward)" % timeit_grad(force))

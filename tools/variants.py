@@ -34,4 +34,4 @@ for name, m in variants.items():
         for i in range(40):
             m(xs[i % 5])
         b.record(); b.synchronize()
-    print("%-40s %.1f us / 1M frames   [%s]" % (name, a.elapsed_time(b) / 40 * 1e3, list(m._plans().values())[-1].plan.last_launch_info()[:28]))
+    print("%-40s %.1f us / 1M frames   [%s]" % (name, a.elapsed_time(b) / 40 * 1e3, __import__('molann_amd.ann').ann.last_launch_info(m)[:28]))
