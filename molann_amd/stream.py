@@ -46,12 +46,18 @@ def _parallel_copy(pool, nthreads, dst, src, columns):
 
 
 def stream_forward(model, frames, chunk_frames=1 << 18, device=None, out=None, columns=None):
-    """Run ``model`` over a host array ``frames`` [N, n_atoms, 3] float32 (numpy array or np.memmap).
+    """Run ``model`` over a host array ``frames`` [N, n_atoms, 3] float32 (numpy array, np.memmap, or a CPU
+    torch tensor).  A PINNED torch tensor (``torch.empty(...).pin_memory()``, e.g. filled by the trajectory
+    reader) is copied to the device straight from where it lies: no staging copy, the link is the only bound.
 
     Returns a host numpy array [N, d_out].  ``columns``: optional list of atom indices to keep on the host
     (the model must then have been built for that reduced input group).
     """
     dev = torch.device(device if device is not None else "cuda")
+    direct = isinstance(frames, torch.Tensor) and frames.is_pinned() and columns is None and \
+        frames.dtype == torch.float32 and frames.is_contiguous()
+    if isinstance(frames, torch.Tensor) and not direct:
+        frames = frames.detach().numpy()
     n = int(frames.shape[0])
     n_atoms = len(columns) if columns is not None else int(frames.shape[1])
     if n == 0:
@@ -59,7 +65,7 @@ def stream_forward(model, frames, chunk_frames=1 << 18, device=None, out=None, c
             d_out = model(torch.zeros((0, n_atoms, 3), device=dev)).shape[1]
         return np.zeros((0, d_out), np.float32)
     chunk = int(min(chunk_frames, n))
-    pin_in = [torch.empty((chunk, n_atoms, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+    pin_in = [None, None] if direct else [torch.empty((chunk, n_atoms, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
     dev_in = [torch.empty((chunk, n_atoms, 3), dtype=torch.float32, device=dev) for _ in range(2)]
     copy_s, comp_s, back_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     in_ready = [torch.cuda.Event() for _ in range(2)]     # H2D of slot done
@@ -69,7 +75,7 @@ def stream_forward(model, frames, chunk_frames=1 << 18, device=None, out=None, c
     starts = list(range(0, n, chunk))
     nthreads = _host_threads()
     pool = ThreadPoolExecutor(max_workers=nthreads)
-    pin_np = [p.numpy() for p in pin_in]
+    pin_np = [None, None] if direct else [p.numpy() for p in pin_in]
 
     def stage(i):
         s = starts[i]
@@ -77,9 +83,10 @@ def stream_forward(model, frames, chunk_frames=1 << 18, device=None, out=None, c
         slot = i & 1
         if i >= 2:
             in_free[slot].synchronize()                   # the pinned + device slot were consumed
-        _parallel_copy(pool, nthreads, pin_np[slot][:m], frames[s:s + m], columns)
+        if not direct:
+            _parallel_copy(pool, nthreads, pin_np[slot][:m], frames[s:s + m], columns)
         with torch.cuda.stream(copy_s):
-            dev_in[slot][:m].copy_(pin_in[slot][:m], non_blocking=True)
+            dev_in[slot][:m].copy_(frames[s:s + m] if direct else pin_in[slot][:m], non_blocking=True)
             in_ready[slot].record(copy_s)
         return m
 

@@ -310,3 +310,6 @@ def test_host_trajectory_streamer(hip_device):
         got = stream_forward(model, x.numpy(), chunk_frames=chunk, device=hip_device)
         assert got.shape == want.shape and np.array_equal(got, want), chunk
     assert stream_forward(model, x.numpy()[:0], device=hip_device).shape == (0, 8)
+    # a pinned torch tensor crosses the link from where it lies (no staging copy); a pageable one is staged
+    assert np.array_equal(stream_forward(model, x.clone().pin_memory(), chunk_frames=3000, device=hip_device), want)
+    assert np.array_equal(stream_forward(model, x, chunk_frames=3000, device=hip_device), want)

@@ -14,3 +14,8 @@ stream_forward(model, x[:1 << 18], device=dev)
 for chunk in (1 << 17, 1 << 18, 1 << 19):
     t = time.perf_counter(); y = stream_forward(model, x, chunk_frames=chunk, device=dev); torch.cuda.synchronize(); dt = time.perf_counter() - t
     print("%s host->host, %d frames, chunk %d: %.1f ms  = %.3g frames/s  (%.1f GB/s over the link)" % (w.name, n, chunk, dt * 1e3, n / dt, n * w.n_atoms * 12 / dt / 1e9))
+xp = torch.from_numpy(x).pin_memory()
+for chunk in (1 << 18, 1 << 19):
+    t = time.perf_counter(); y2 = stream_forward(model, xp, chunk_frames=chunk, device=dev); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("%s pinned host->host, %d frames, chunk %d: %.1f ms  = %.3g frames/s  (%.1f GB/s over the link)" % (w.name, n, chunk, dt * 1e3, n / dt, n * w.n_atoms * 12 / dt / 1e9))
+assert np.array_equal(y, y2)
