@@ -126,7 +126,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("MOLANN_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL calls on one rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -158,7 +158,7 @@ def main():
             y = model(xs[i % nbuf])
         if distributed and not args.no_gather:
             from molann_amd.dist import all_gather_outputs
-            all_gather_outputs(y)
+            all_gather_outputs(y, frames * world)   # equal shards: no size exchange, one collective
         torch.cuda.synchronize()
 
         ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -170,7 +170,7 @@ def main():
             y = model(xs[i % nbuf])
         ev1.record()
         if distributed and not args.no_gather:
-            y_all = all_gather_outputs(y)
+            y_all = all_gather_outputs(y, frames * world)
         ev2.record()
         torch.cuda.synchronize()
         barrier()
