@@ -188,6 +188,8 @@ int molann_debug_read_stamps(unsigned long long* out8);
 /* Self-test hooks: the __host__ __device__ math the kernels are built from, compiled for the HOST, so
  * the CPU test-suite can check it against the oracle without a GPU.  Not a product path. */
 int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9);
+/* the fp32 instantiation of the same solver (plans whose items are all bond / angle / dihedral) */
+int molann_selftest_kabsch_rotation_f32(const float* H9, float e0, float* R9);
 int molann_selftest_feature(int type, int use_angle_value, const float* atoms_xyz, float* out3);
 float molann_selftest_activation(int act, float v);
 int molann_selftest_feature_backward(int type, int use_angle_value, const float* atoms_xyz, const float* g3, float* ga12);

@@ -87,6 +87,7 @@ def lib():
             "molann_debug_read_stamps": (i32, [vp]),
             "molann_debug_jit": (i32, [ctypes.POINTER(PlanDesc), i32, ctypes.c_char_p, i32]),
             "molann_selftest_kabsch_rotation": (i32, [vp, ctypes.c_double, vp]),
+            "molann_selftest_kabsch_rotation_f32": (i32, [vp, f32, vp]),
             "molann_selftest_feature": (i32, [i32, i32, vp, vp]),
             "molann_selftest_activation": (f32, [i32, f32]),
             "molann_selftest_feature_backward": (i32, [i32, i32, vp, vp, vp]),

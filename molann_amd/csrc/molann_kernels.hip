@@ -1286,6 +1286,11 @@ std::string jit_preamble(const JitSpec& j) {
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
     s += (debug_env().ablate & 32) ? "constexpr bool STAMPS = true;\n" : "constexpr bool STAMPS = false;\n";
+    // diagnostic (MOLANN_DEBUG_ABLATE bit 64): every wave stages its first tile only and recomputes it for all its
+    // tiles - the kernel's compute time without the HBM stream
+    s += (debug_env().ablate & 64) ? "constexpr bool NO_RESTAGE = true;\n" : "constexpr bool NO_RESTAGE = false;\n";
+    // diagnostic (bit 128): the whole next tile's LDS-DMA right after the register fill instead of in slices
+    s += (debug_env().ablate & 128) ? "constexpr bool DMA_EARLY = true;\n" : "constexpr bool DMA_EARLY = false;\n";
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
@@ -1368,11 +1373,12 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         lds += (size_t)debug_env().lds_pad; // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
-        if (mode == 0 && p->jit_fn && (a.ablate & ~32) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
             unsigned long long* stamps = nullptr;
             if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
             struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
-                     unsigned long long* stamps; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide, a.out_vec4, stamps};
+                     unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
+                                                                            a.out_vec4, stamps, p->d_ref};
             size_t ksz = sizeof(ka);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
             const hipError_t le = hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, 64 * wpb, 1, 1, (unsigned)lds, stream, nullptr, cfg);
@@ -2098,6 +2104,15 @@ int molann_selftest_kabsch_rotation(const double* H9, double e0, float* R9) {
     float r[9];
     for (int i = 0; i < 9; ++i) h[i] = H9[i];
     kabsch_rotation(h, e0, r);
+    for (int i = 0; i < 9; ++i) R9[i] = r[i];
+    return MOLANN_OK;
+}
+
+int molann_selftest_kabsch_rotation_f32(const float* H9, float e0, float* R9) {
+    if (!H9 || !R9) return MOLANN_E_NULL;
+    float h[9], r[9];
+    for (int i = 0; i < 9; ++i) h[i] = H9[i];
+    kabsch_rotation_f32(h, e0, r);
     for (int i = 0; i < 9; ++i) R9[i] = r[i];
     return MOLANN_OK;
 }

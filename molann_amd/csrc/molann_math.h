@@ -173,59 +173,74 @@ MOLANN_HD float apply_activation(int act, float v) {
 // reference, three align atoms) and reflections need no special case.  lambda_max by Newton on the
 // characteristic quartic from above (monotone), eigenvector = the column of adj(K - lambda I) with the
 // largest diagonal entry.  fp64 throughout: ~250 flops per frame, against ~60 flops to form H.
-MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) {
-    double fro2 = 0.0;
+MOLANN_HD float tfma(float a, float b, float c) { return fmaf(a, b, c); }
+MOLANN_HD double tfma(double a, double b, double c) { return fma(a, b, c); }
+MOLANN_HD float tabs(float a) { return fabsf(a); }
+MOLANN_HD double tabs(double a) { return fabs(a); }
+
+// T = double: what every plan with position items (and AlignmentLayer.forward) uses.  T = float: the same
+// algorithm at the reference's own precision (its SVD runs in fp32) for plans whose items are all invariant
+// under rigid motion (bond / angle / dihedral): their outputs do not depend on how accurate R is, only on R
+// being a proper rotation, which the normalised quaternion guarantees in either precision.
+template <typename T>
+MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, float (&R)[9]) {
+    constexpr bool F32 = sizeof(T) == 4;
+    const T tiny = F32 ? (T)1e-30f : (T)1e-30, huge = F32 ? (T)1e30f : (T)1e30;
+    T fro2 = (T)0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) fro2 = fma(H[i], H[i], fro2);
-    if (!(fro2 > 1e-30) || !(fro2 < 1e30)) { // zero / non-finite covariance: no rotation
+    for (int i = 0; i < 9; ++i) fro2 = tfma(H[i], H[i], fro2);
+    if (!(fro2 > tiny) || !(fro2 < huge)) { // zero / non-finite covariance: no rotation
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
         return;
     }
     // scale so that |h|_F ~= 1: the rotation does not depend on the scale, so an fp32 rsqrt is enough
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double s = (double)__builtin_amdgcn_rsqf((float)fro2);
+    const T s = (T)__builtin_amdgcn_rsqf((float)fro2);
 #else
-    const double s = (double)(1.0f / sqrtf((float)fro2));
+    const T s = (T)(1.0f / sqrtf((float)fro2));
 #endif
-    const double hxx = H[0] * s, hxy = H[1] * s, hxz = H[2] * s;
-    const double hyx = H[3] * s, hyy = H[4] * s, hyz = H[5] * s;
-    const double hzx = H[6] * s, hzy = H[7] * s, hzz = H[8] * s;
+    const T hxx = H[0] * s, hxy = H[1] * s, hxz = H[2] * s;
+    const T hyx = H[3] * s, hyy = H[4] * s, hyz = H[5] * s;
+    const T hzx = H[6] * s, hzy = H[7] * s, hzz = H[8] * s;
 
-    const double k00 = hxx + hyy + hzz, k01 = hyz - hzy, k02 = hzx - hxz, k03 = hxy - hyx;
-    const double k11 = hxx - hyy - hzz, k12 = hxy + hyx, k13 = hzx + hxz;
-    const double k22 = -hxx + hyy - hzz, k23 = hyz + hzy;
-    const double k33 = -hxx - hyy + hzz;
+    const T k00 = hxx + hyy + hzz, k01 = hyz - hzy, k02 = hzx - hxz, k03 = hxy - hyx;
+    const T k11 = hxx - hyy - hzz, k12 = hxy + hyx, k13 = hzx + hxz;
+    const T k22 = -hxx + hyy - hzz, k23 = hyz + hzy;
+    const T k33 = -hxx - hyy + hzz;
 
     // characteristic polynomial l^4 + c2 l^2 + c1 l + c0 (trace K = 0)
-    const double c2 = -2.0 * (hxx * hxx + hxy * hxy + hxz * hxz + hyx * hyx + hyy * hyy + hyz * hyz + hzx * hzx +
+    const T c2 = (T)-2 * (hxx * hxx + hxy * hxy + hxz * hxz + hyx * hyx + hyy * hyy + hyz * hyz + hzx * hzx +
                               hzy * hzy + hzz * hzz);
-    const double det_h = hxx * (hyy * hzz - hyz * hzy) - hxy * (hyx * hzz - hyz * hzx) + hxz * (hyx * hzy - hyy * hzx);
-    const double c1 = -8.0 * det_h;
-    double c0;
+    const T det_h = hxx * (hyy * hzz - hyz * hzy) - hxy * (hyx * hzz - hyz * hzx) + hxz * (hyx * hzy - hyy * hzx);
+    const T c1 = (T)-8 * det_h;
+    T c0;
     {
-        const double s0 = k00 * k11 - k01 * k01, s1 = k00 * k12 - k01 * k02, s2 = k00 * k13 - k01 * k03;
-        const double s3 = k01 * k12 - k11 * k02, s4 = k01 * k13 - k11 * k03, s5 = k02 * k13 - k12 * k03;
-        const double d5 = k22 * k33 - k23 * k23, d4 = k12 * k33 - k13 * k23, d3 = k12 * k23 - k13 * k22;
-        const double d2 = k02 * k33 - k03 * k23, d1 = k02 * k23 - k03 * k22, d0 = k02 * k13 - k03 * k12;
+        const T s0 = k00 * k11 - k01 * k01, s1 = k00 * k12 - k01 * k02, s2 = k00 * k13 - k01 * k03;
+        const T s3 = k01 * k12 - k11 * k02, s4 = k01 * k13 - k11 * k03, s5 = k02 * k13 - k12 * k03;
+        const T d5 = k22 * k33 - k23 * k23, d4 = k12 * k33 - k13 * k23, d3 = k12 * k23 - k13 * k22;
+        const T d2 = k02 * k33 - k03 * k23, d1 = k02 * k23 - k03 * k22, d0 = k02 * k13 - k03 * k12;
         c0 = s0 * d5 - s1 * d4 + s2 * d3 + s3 * d2 - s4 * d1 + s5 * d0;
     }
 
     // Newton from above; lambda_max <= s1+s2+s3 <= sqrt(3) |h|_F and <= e0 * s
-    double lam = fmin(e0 * s, 1.7320508075688772);
-    if (!(lam > 0.0)) lam = 1.7320508075688772;
+    constexpr T sqrt3 = (T)1.7320508075688772;
+    T lam = e0 * s < sqrt3 ? e0 * s : sqrt3;
+    if (!(lam > (T)0)) lam = sqrt3;
     bool done = false;
-    for (int it = 0; it < 48; ++it) { // bounded: every lane reaches the exit
+    // bounded: every lane reaches the exit.  fp32: the residual's own rounding (~1e-7 / p'(lam)) keeps an
+    // ill-conditioned frame from ever meeting the step test, so the cap is what ends it there.
+    for (int it = 0; it < (F32 ? 12 : 48); ++it) {
         if (!done) {
-            const double l2 = lam * lam;
-            const double p = (l2 + c2) * l2 + c1 * lam + c0;
-            const double dp = (4.0 * l2 + 2.0 * c2) * lam + c1;
+            const T l2 = lam * lam;
+            const T p = (l2 + c2) * l2 + c1 * lam + c0;
+            const T dp = ((T)4 * l2 + (T)2 * c2) * lam + c1;
             // Newton corrects itself: an fp32-accurate reciprocal is enough
-            const double step = p * (double)fast_rcp((float)dp);
-            const double nl = lam - step;
-            const bool finite = (step == step) && (fabs(nl) < 4.0);
+            const T step = p * (T)fast_rcp((float)dp);
+            const T nl = lam - step;
+            const bool finite = (step == step) && (tabs(nl) < (T)4);
             if (finite) lam = nl;
-            if (!finite || !(fabs(step) > 1e-14 * fabs(nl))) done = true;
+            if (!finite || !(tabs(step) > (F32 ? (T)1e-6f : (T)1e-14) * tabs(nl))) done = true;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         if (__all(done)) break; // wave-uniform exit
@@ -235,50 +250,53 @@ MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) {
     }
 
     // adj(K - lam I) = const * q q^T
-    const double m00 = k00 - lam, m11 = k11 - lam, m22 = k22 - lam, m33 = k33 - lam;
-    const double s0 = m00 * m11 - k01 * k01, s1 = m00 * k12 - k01 * k02, s2 = m00 * k13 - k01 * k03;
-    const double s3 = k01 * k12 - m11 * k02, s4 = k01 * k13 - m11 * k03, s5 = k02 * k13 - k12 * k03;
-    const double d5 = m22 * m33 - k23 * k23, d4 = k12 * m33 - k13 * k23, d3 = k12 * k23 - k13 * m22;
-    const double d2 = k02 * m33 - k03 * k23, d1 = k02 * k23 - k03 * m22;
-    const double a00 = m11 * d5 - k12 * d4 + k13 * d3;
-    const double a01 = -k01 * d5 + k02 * d4 - k03 * d3;
-    const double a02 = k13 * s5 - k23 * s4 + m33 * s3;
-    const double a03 = -k12 * s5 + m22 * s4 - k23 * s3;
-    const double a11 = m00 * d5 - k02 * d2 + k03 * d1;
-    const double a12 = -k03 * s5 + k23 * s2 - m33 * s1;
-    const double a13 = k02 * s5 - m22 * s2 + k23 * s1;
-    const double a22 = k03 * s4 - k13 * s2 + m33 * s0;
-    const double a23 = -k02 * s4 + k12 * s2 - k23 * s0;
-    const double a33 = k02 * s3 - k12 * s1 + m22 * s0;
+    const T m00 = k00 - lam, m11 = k11 - lam, m22 = k22 - lam, m33 = k33 - lam;
+    const T s0 = m00 * m11 - k01 * k01, s1 = m00 * k12 - k01 * k02, s2 = m00 * k13 - k01 * k03;
+    const T s3 = k01 * k12 - m11 * k02, s4 = k01 * k13 - m11 * k03, s5 = k02 * k13 - k12 * k03;
+    const T d5 = m22 * m33 - k23 * k23, d4 = k12 * m33 - k13 * k23, d3 = k12 * k23 - k13 * m22;
+    const T d2 = k02 * m33 - k03 * k23, d1 = k02 * k23 - k03 * m22;
+    const T a00 = m11 * d5 - k12 * d4 + k13 * d3;
+    const T a01 = -k01 * d5 + k02 * d4 - k03 * d3;
+    const T a02 = k13 * s5 - k23 * s4 + m33 * s3;
+    const T a03 = -k12 * s5 + m22 * s4 - k23 * s3;
+    const T a11 = m00 * d5 - k02 * d2 + k03 * d1;
+    const T a12 = -k03 * s5 + k23 * s2 - m33 * s1;
+    const T a13 = k02 * s5 - m22 * s2 + k23 * s1;
+    const T a22 = k03 * s4 - k13 * s2 + m33 * s0;
+    const T a23 = -k02 * s4 + k12 * s2 - k23 * s0;
+    const T a33 = k02 * s3 - k12 * s1 + m22 * s0;
 
     // column with the largest |diagonal| (q_j^2 >= 1/4 there)
-    double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
-    if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
-    if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
-    if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
-    const double n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
-    if (!(n2 > 1e-30) || !(n2 < 1e30)) { // K - lam I numerically zero: degenerate input
+    T q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = tabs(a00);
+    if (tabs(a11) > best) { best = tabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+    if (tabs(a22) > best) { best = tabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+    if (tabs(a33) > best) { best = tabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+    const T n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    if (!(n2 > tiny) || !(n2 < huge)) { // K - lam I numerically zero: degenerate input
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
         return;
     }
     // 1/n2: fp32 reciprocal seed + one Newton step in fp64 (relative error ~1e-14)
-    double inv = (double)fast_rcp((float)n2);
-    inv = inv * (2.0 - n2 * inv);
-    const double ww = q0 * q0 * inv, xx = q1 * q1 * inv, yy = q2 * q2 * inv, zz = q3 * q3 * inv;
-    const double wx = q0 * q1 * inv, wy = q0 * q2 * inv, wz = q0 * q3 * inv;
-    const double xy = q1 * q2 * inv, xz = q1 * q3 * inv, yz = q2 * q3 * inv;
+    T inv = (T)fast_rcp((float)n2);
+    inv = inv * ((T)2 - n2 * inv);
+    const T ww = q0 * q0 * inv, xx = q1 * q1 * inv, yy = q2 * q2 * inv, zz = q3 * q3 * inv;
+    const T wx = q0 * q1 * inv, wy = q0 * q2 * inv, wz = q0 * q3 * inv;
+    const T xy = q1 * q2 * inv, xz = q1 * q3 * inv, yz = q2 * q3 * inv;
     // Q (column convention, maps frame -> reference); R = Q^T for row vectors
     R[0] = (float)(ww + xx - yy - zz);
-    R[1] = (float)(2.0 * (xy + wz));
-    R[2] = (float)(2.0 * (xz - wy));
-    R[3] = (float)(2.0 * (xy - wz));
+    R[1] = (float)((T)2 * (xy + wz));
+    R[2] = (float)((T)2 * (xz - wy));
+    R[3] = (float)((T)2 * (xy - wz));
     R[4] = (float)(ww - xx + yy - zz);
-    R[5] = (float)(2.0 * (yz + wx));
-    R[6] = (float)(2.0 * (xz + wy));
-    R[7] = (float)(2.0 * (yz - wx));
+    R[5] = (float)((T)2 * (yz + wx));
+    R[6] = (float)((T)2 * (xz + wy));
+    R[7] = (float)((T)2 * (yz - wx));
     R[8] = (float)(ww - xx - yy + zz);
 }
+
+MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) { kabsch_rotation_t<double>(H, e0, R); }
+MOLANN_HD void kabsch_rotation_f32(const float (&H)[9], float e0, float (&R)[9]) { kabsch_rotation_t<float>(H, e0, R); }
 
 // y = p . R  (row vector times row-major R)
 MOLANN_HD V3 rotate(V3 p, const float (&R)[9]) {

@@ -99,6 +99,42 @@ def test_kabsch_rotation_degenerate_inputs_are_finite():
         assert abs(np.linalg.det(R.reshape(3, 3).astype(np.float64)) - 1.0) < 1e-5
 
 
+def test_kabsch_rotation_f32_instantiation():
+    """The fp32 instantiation (plans whose items are all invariant): always a proper rotation, and on
+    well-conditioned covariances within fp32 rounding (times the conditioning) of the fp64 one."""
+    L = _capi.lib()
+    g = np.random.default_rng(11)
+    worst = 0.0
+    for i in range(400):
+        a = int(g.integers(3, 9))
+        ref = g.normal(size=(a, 3)) * 2
+        ref -= ref.mean(0)
+        q = g.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        Q = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        P = ref @ Q + 0.2 * g.normal(size=(a, 3))
+        P -= P.mean(0)
+        H = np.ascontiguousarray((P.T @ ref).reshape(9))
+        e0 = 0.5 * ((P * P).sum() + (ref * ref).sum()) * 1.0001
+        R64, R32 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        assert L.molann_selftest_kabsch_rotation(_ptr(H), e0, _ptr(R64)) == 0
+        H32 = H.astype(np.float32)
+        assert L.molann_selftest_kabsch_rotation_f32(_ptr(H32), np.float32(e0), _ptr(R32)) == 0
+        M = R32.reshape(3, 3).astype(np.float64)
+        assert np.abs(M @ M.T - np.eye(3)).max() < 2e-6 and abs(np.linalg.det(M) - 1.0) < 2e-6
+        sv = np.linalg.svd(H.reshape(3, 3), compute_uv=False)
+        d = np.sign(np.linalg.det(H.reshape(3, 3)))
+        if (sv[1] + d * sv[2]) / sv[0] > 0.2:               # well-defined rotation
+            worst = max(worst, np.abs(R32 - R64).max())
+    assert worst < 2e-5, worst
+    for H in (np.zeros(9, np.float32), np.full(9, np.nan, np.float32), np.array([1, 0, 0, 0, 0, 0, 0, 0, 0], np.float32)):
+        R = np.zeros(9, np.float32)
+        assert L.molann_selftest_kabsch_rotation_f32(_ptr(H), np.float32(1.0), _ptr(R)) == 0
+        assert np.isfinite(R).all() and abs(np.linalg.det(R.reshape(3, 3).astype(np.float64)) - 1.0) < 1e-5
+
+
 # ---- reverse mode: the analytic gradients against torch autograd of the oracle (fp64) ----------------------
 @pytest.mark.parametrize("type_id,n_atoms", [(0, 3), (1, 2), (2, 4), (3, 1)])
 @pytest.mark.parametrize("uav", [False, True])
