@@ -11,9 +11,10 @@ in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
 
 There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 tensor that lives
 on a HIP device raises.  Gradients (w.r.t. x and the Linear parameters) come from a hand-written backward
-kernel for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32); where that
-kernel does not apply (large frames, wide MLPs, `AlignmentLayer` on its own) a forward that would have to
-record gradients raises NotImplementedError: run it under ``torch.no_grad()``.
+kernel for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32).  With a wider MLP
+(or ELU / GELU / Softplus) on small frames a forward under grad mode takes features and their gradient from
+the kernels and runs ``ann_layers`` as the torch module it is; on large frames (wave-per-frame kernel) a
+forward that would have to record gradients raises NotImplementedError: run it under ``torch.no_grad()``.
 """
 
 import torch
@@ -564,10 +565,13 @@ class MolANN(_PlanOwner, torch.nn.Module):
                 if al is not None:
                     entry.sync_ref(_device_buffer(al.ref_x, x))
                 entry.sync_mlp(st["linears"])
-                if not entry.plan.supports_backward():
-                    raise NotImplementedError("no backward kernel for this plan (wide MLP / large frames / this "
-                                              "activation): call it under torch.no_grad()")
-                return _PlanFunction.apply(x, entry, True, *st["params"])
+                if entry.plan.supports_backward():
+                    return _PlanFunction.apply(x, entry, True, *st["params"])
+            # No fused backward kernel (MLP wider than 32 / ELU, GELU, Softplus).  Training still works when the
+            # preprocessing has one (small frames): features and their gradient from the HIP kernels, the MLP and
+            # its gradient as the user's own torch module on the device - what already happens for ann_layers
+            # this file does not recognise.  Large frames raise inside the preprocessing layer.
+            return self.ann_layers(self.preprocessing_layer(x))
         w0 = st["linears"][0].weight
         if w0.device != x.device or w0.dtype != torch.float32:
             raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))

@@ -155,7 +155,53 @@ def test_alignment_layer_gradient(hip_device):
     assert float((x.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * scale
 
 
-def test_plans_without_a_backward_kernel_raise(hip_device):
+def test_large_frames_raise_only_when_x_needs_grad(hip_device):
+    """Wave-per-frame plans have no backward kernel: a gradient w.r.t. x raises; training the MLP alone works
+    (features from the gather kernel, ann_layers as the torch module it is)."""
     big = wl.get_workload("C4")
+    model = wl.build_model(big, hip_device)
+    x = big.make_frames(4, seed=3).to(hip_device)
     with pytest.raises(NotImplementedError):
-        wl.build_model(big, hip_device)(big.make_frames(2).to(hip_device))   # large frames, parameters need grad
+        model(x.clone().requires_grad_(True))
+    y = model(x)
+    assert y.requires_grad
+    y.sum().backward()
+    lin = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in lin)
+    with torch.no_grad():
+        assert float((y - model(x)).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
+
+
+@pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.GELU])
+def test_wide_mlp_trains_through_hip_features(act, hip_device):
+    """MLP wider than the fused backward kernel covers: feature gradients from the HIP kernels, the MLP and its
+    gradient from torch; all of it against autograd through the fp64 oracle."""
+    w = wl.get_workload("C3")
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], U.atoms_by_number(atoms)) for i, (t, atoms) in enumerate(w.features)]
+    al = AlignmentLayer(U.atoms_by_number(w.align), U.atoms)
+    pp = PreprocessingANN(al, FeatureLayer(feats, U.atoms, False))
+    torch.manual_seed(5)
+    model = MolANN(pp, create_sequential_nn([6, 64, 48, 4], activation=act())).to(hip_device)
+    x = w.make_frames(500, seed=9)
+    xg = x.to(hip_device).requires_grad_(True)
+    G = torch.randn((500, 4), generator=torch.Generator().manual_seed(1))
+    y = model(xg)
+    (y * G.to(hip_device)).sum().backward()
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    xx = x.double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[[a - 1 for a in w.align]])).double()
+    f = mo.preprocessing_forward(xx, [(t, [a - 1 for a in atoms]) for t, atoms in w.features], False,
+                                 [a - 1 for a in w.align], ref_x)
+    h = f
+    for i, (wt, b) in enumerate(zip(ws, bs)):
+        h = h @ wt.T + b
+        if i + 1 < len(ws):
+            h = act()(h)
+    (h * G.double()).sum().backward()
+    assert float((y.detach().cpu().double() - h.detach()).abs().max()) <= 1e-4
+    for got, want in [(xg.grad, xx.grad)] + [(l.weight.grad, wt.grad) for l, wt in zip(lins, ws)] + \
+                     [(l.bias.grad, b.grad) for l, b in zip(lins, bs)]:
+        scale = max(1e-6, float(want.abs().max()))
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-4 * scale
