@@ -164,7 +164,8 @@ int molann_plan_supports_backward(const molann_plan* plan);
  * may be NULL) and grad_params (ACCUMULATED into with float atomics, so zero it first; may be NULL).
  * Nothing is saved from the forward: the kernel recomputes it.  Available for plans served by the
  * lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU / sigmoid / identity / SiLU /
- * LeakyReLU; otherwise MOLANN_E_UNSUPPORTED.  Compiled with hipRTC at the first call. */
+ * LeakyReLU (compiled with hipRTC at the first call), and for feature plans without an MLP on large frames
+ * (one wave per frame, float atomics into the zeroed gradient row); otherwise MOLANN_E_UNSUPPORTED. */
 int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* grad_x,
                         float* grad_params, molann_stream_t stream);
 

@@ -700,6 +700,132 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
 }
 
 // =============================================================================================
+// frames_wave_bwd_kernel: dL/dx of frames_wave_kernel (features of large frames), one wave per frame
+// =============================================================================================
+// grad_out[f][d_feat] -> grad_x[f][n_inp][3].  The frame's gradient row is zeroed with coalesced stores, then
+// every contribution is a float atomic into it (an atom may sit in several items and in the alignment set).
+//   items (lanes):  y_j = ((p_j - c0) - dl) R ;  g_y from eval_item_backward ;  g_p = g_y R^T ;
+//                   G_R += (p_j - c)^T g_y ;  g_sum += g_p
+//   wave:           G_R, g_sum reduced ;  G_H = kabsch_rotation_backward(H, R, G_R)
+//   align atoms:    g_p[i] += G_H ref_i - g_sum / a        (H = sum_i p_i ref_i^T, c = mean of the align atoms)
+// The forward quantities (c, H, R) are recomputed exactly as frames_wave_kernel computes them.
+__global__ __launch_bounds__(256) void frames_wave_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                              float* __restrict__ gx, const int* __restrict__ align_idx,
+                                                              const float* __restrict__ ref, const double* __restrict__ ref64,
+                                                              const ItemDev* __restrict__ items, PreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const auto refc = as_const(ref);
+    const bool has_align = a.n_align > 0;
+
+    for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
+        const float* xf = x + f * (long)a.frame_dw;
+        float* gxf = gx + f * (long)a.frame_dw;
+        const float* gf = gout + f * (long)a.out_cols;
+        // ---- 0. zero this frame's gradient row; the stores must have landed before the atomics below
+        if (a.out_wide && (a.frame_dw & 3) == 0) {
+            for (int c = lane; c < (a.frame_dw >> 2); c += 64) ((f32x4*)gxf)[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int c = lane; c < a.frame_dw; c += 64) gxf[c] = 0.f;
+        }
+        // ---- 1. forward recompute: centre, covariance, rotation
+        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+        V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        if (has_align) {
+            const int k0 = as_const(align_idx)[0];
+            c0 = load_atom(xf, k0);
+            float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
+#pragma unroll 4
+            for (int i = lane; i < a.n_align; i += 64) {
+                const int k = align_idx[i];
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3 p = load_atom(xf, k) - c0;
+                sx += p.x; sy += p.y; sz += p.z;
+                g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
+                const double px = p.x, py = p.y, pz = p.z;
+                h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
+                h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
+                h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            }
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            const int cb = 3 * a.n_align;
+            const auto r64c = as_const(ref64);
+            const double srx = r64c[cb], sry = r64c[cb + 1], srz = r64c[cb + 2], gref = r64c[cb + 3];
+            const float inv_a = refc[cb + 4], fa = refc[cb + 5];
+            dl = v3(sx * inv_a, sy * inv_a, sz * inv_a);
+            const double dx = dl.x, dy = dl.y, dz = dl.z;
+            h[0] = fma(-dx, srx, h[0]); h[1] = fma(-dx, sry, h[1]); h[2] = fma(-dx, srz, h[2]);
+            h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
+            h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
+            const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zero stores are acknowledged
+
+        // ---- 2. items
+        float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        V3 gsum = v3(0.f, 0.f, 0.f);
+        for (int it = lane; it < a.n_items; it += 64) {
+            const int4 d0 = ((const int4*)items)[2 * it];
+            const int2 d1 = ((const int2*)items)[4 * it + 2];
+            const int type = d0.x, col = d0.y;
+            const int idx[4] = {d0.z, d0.w, d1.x, d1.y};
+            V3 pc[4], y[4], gy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pc[j] = load_atom(xf, idx[j]);
+                if (has_align) pc[j] = (pc[j] - c0) - dl;
+                y[j] = has_align ? rotate(pc[j], R) : pc[j];
+                gy[j] = v3(0.f, 0.f, 0.f);
+            }
+            const int w = item_width(type);
+            float g3[3] = {gf[col], w > 1 ? gf[col + 1] : 0.f, w > 2 ? gf[col + 2] : 0.f};
+            eval_item_backward(type, y[0], y[1], y[2], y[3], g3, gy[0], gy[1], gy[2], gy[3]);
+            const int na = item_atoms(type);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < na) {
+                    const V3 g = gy[j];
+                    V3 gp = g;
+                    if (has_align) { // y = pc R :  G_R += pc^T g ,  g_p = g R^T
+                        GR[0] = fmaf(pc[j].x, g.x, GR[0]); GR[1] = fmaf(pc[j].x, g.y, GR[1]); GR[2] = fmaf(pc[j].x, g.z, GR[2]);
+                        GR[3] = fmaf(pc[j].y, g.x, GR[3]); GR[4] = fmaf(pc[j].y, g.y, GR[4]); GR[5] = fmaf(pc[j].y, g.z, GR[5]);
+                        GR[6] = fmaf(pc[j].z, g.x, GR[6]); GR[7] = fmaf(pc[j].z, g.y, GR[7]); GR[8] = fmaf(pc[j].z, g.z, GR[8]);
+                        gp = v3(fmaf(g.z, R[2], fmaf(g.y, R[1], g.x * R[0])), fmaf(g.z, R[5], fmaf(g.y, R[4], g.x * R[3])),
+                                fmaf(g.z, R[8], fmaf(g.y, R[7], g.x * R[6])));
+                        gsum = gsum + gp;
+                    }
+                    float* dst = gxf + 3 * idx[j];
+                    atomicAdd(dst, gp.x); atomicAdd(dst + 1, gp.y); atomicAdd(dst + 2, gp.z);
+                }
+            }
+        }
+        // ---- 3. rotation and centring backward through the alignment atoms
+        if (has_align) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) GR[i] = wave_sum(GR[i]);
+            gsum = v3(wave_sum(gsum.x), wave_sum(gsum.y), wave_sum(gsum.z));
+            float GH[9];
+            kabsch_rotation_backward(h, R, GR, GH);
+            const float inv_a = refc[3 * a.n_align + 4];
+            const V3 gcen = inv_a * gsum;
+            for (int i = lane; i < a.n_align; i += 64) {
+                const int k = align_idx[i];
+                const float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+                const V3 add = v3(fmaf(GH[2], rz, fmaf(GH[1], ry, GH[0] * rx)), fmaf(GH[5], rz, fmaf(GH[4], ry, GH[3] * rx)),
+                                  fmaf(GH[8], rz, fmaf(GH[7], ry, GH[6] * rx))) - gcen;
+                float* dst = gxf + 3 * k;
+                atomicAdd(dst, add.x); atomicAdd(dst + 1, add.y); atomicAdd(dst + 2, add.z);
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // mlp_mfma_kernel: wide MLP over precomputed features, one wave per 16-frame row block
 // =============================================================================================
 // Packed weights, layer l (fp32 path): Wp[Jp][Kp] row-major (torch.nn.Linear layout, zero padded to
@@ -1945,6 +2071,7 @@ int molann_plan_grad_params_size(const molann_plan* p) { return p ? p->n_grad_pa
 
 int molann_plan_supports_backward(const molann_plan* p) {
     if (!p) return MOLANN_E_NULL;
+    if (!p->geom[0].ok && p->n_items > 0 && p->n_layers == 0) return 1; // large frames, features only: frames_wave_bwd_kernel
     if (!p->spec || p->n_items <= 0 || p->bwd_state < 0 || !rtc_api()->ok) return 0;
     if (p->n_layers > 0 && !p->fused_mlp) return 0;
     const int act = p->act;
@@ -1959,6 +2086,18 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
     if (n < 0) return MOLANN_E_DESC;
     if (n == 0) return MOLANN_OK;
     if (!x || !grad_out) return MOLANN_E_NULL;
+    if (!p->geom[0].ok && p->n_items > 0 && p->n_layers == 0) { // large frames: one wave per frame, no parameters
+        if (!grad_x) return MOLANN_OK;
+        if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_x) & 3)) return MOLANN_E_ALIGNMENT;
+        PreArgs a;
+        fill_pre_args(p, a, n, 0, p->d_feat, false, x, grad_x);
+        const int wpb = 4;
+        const int grid = grid_for(p, n, wpb, 8);
+        hipLaunchKernelGGL(frames_wave_bwd_kernel, dim3(grid), dim3(64 * wpb), 0, (hipStream_t)stream, x, grad_out, grad_x,
+                           p->d_align_idx, p->d_ref, p->d_ref64, p->d_items, a);
+        snprintf(p->last_info, sizeof(p->last_info), "frames_wave_bwd_kernel grid=%d block=%d", grid, 64 * wpb);
+        return (int)hipGetLastError();
+    }
     if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
     const int act = p->act;
     if (p->spec->j.n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return MOLANN_E_UNSUPPORTED;

@@ -332,8 +332,56 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
     }
 };
 
+// the plan of `desc` without its MLP (what PreprocessingANN.forward launches)
+std::vector<int64_t> features_only(const std::vector<int64_t>& desc) {
+    const int64_t n_layers = desc[6];
+    std::vector<int64_t> v(desc.begin(), desc.end() - (n_layers > 0 ? n_layers + 1 : 0));
+    v[1] = KIND_FEATURES;
+    v[6] = 0;
+    return v;
+}
+
+at::Tensor activation(int64_t code, const at::Tensor& t) {
+    switch (code) {
+    case MOLANN_ACT_TANH: return at::tanh(t);
+    case MOLANN_ACT_RELU: return at::relu(t);
+    case MOLANN_ACT_SIGMOID: return at::sigmoid(t);
+    case MOLANN_ACT_IDENTITY: return t;
+    case MOLANN_ACT_ELU: return at::elu(t);
+    case MOLANN_ACT_SILU: return at::silu(t);
+    case MOLANN_ACT_SOFTPLUS: return at::softplus(t);
+    case MOLANN_ACT_LEAKY_RELU: return at::leaky_relu(t, 0.01);
+    case MOLANN_ACT_GELU: return at::gelu(t);
+    default: TORCH_CHECK(false, "molann::run: unknown activation code ", code);
+    }
+}
+
 at::Tensor run_autograd(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
                         std::vector<at::Tensor> biases) {
+    // A fused plan without a backward kernel (MLP wider than 32, large frames, ELU / GELU / Softplus) that has to
+    // record gradients: features and their gradient from the kernels (the plan without the MLP), the MLP as ATen
+    // ops - the composition molann_amd/ann.py: MolANN.forward uses in the same situation.
+    if (desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD && at::GradMode::is_enabled() && x.is_cuda()) {
+        bool needs = x.requires_grad();
+        for (const auto& w : weights) needs = needs || w.requires_grad();
+        for (const auto& b : biases) needs = needs || b.requires_grad();
+        if (needs) {
+            check_x(x, desc);
+            bool fused_backward;
+            {
+                const c10::DeviceGuard guard(x.device());
+                fused_backward = molann_plan_supports_backward(entry_for(desc, x, ref_x)->plan) == 1;
+            }
+            if (!fused_backward) {
+                at::Tensor h = call_run(x, features_only(desc), ref_x, {}, {});
+                for (size_t l = 0; l < weights.size(); ++l) {
+                    h = at::linear(h, weights[l], biases[l]);
+                    if (l + 1 < weights.size()) h = activation(desc[7], h);
+                }
+                return h;
+            }
+        }
+    }
     return RunFunction::apply(x, desc, ref_x, at::TensorList(weights), at::TensorList(biases));
 }
 

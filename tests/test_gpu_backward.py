@@ -155,21 +155,54 @@ def test_alignment_layer_gradient(hip_device):
     assert float((x.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * scale
 
 
-def test_large_frames_raise_only_when_x_needs_grad(hip_device):
-    """Wave-per-frame plans have no backward kernel: a gradient w.r.t. x raises; training the MLP alone works
-    (features from the gather kernel, ann_layers as the torch module it is)."""
-    big = wl.get_workload("C4")
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_large_frames_gradients(cfg, hip_device):
+    """Wave-per-frame plans: dL/dx from frames_wave_bwd_kernel (features) chained with the torch MLP, parameter
+    gradients from torch; against autograd through the fp64 oracle."""
+    big = wl.get_workload(cfg)
     model = wl.build_model(big, hip_device)
-    x = big.make_frames(4, seed=3).to(hip_device)
-    with pytest.raises(NotImplementedError):
-        model(x.clone().requires_grad_(True))
-    y = model(x)
-    assert y.requires_grad
-    y.sum().backward()
-    lin = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
-    assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in lin)
-    with torch.no_grad():
-        assert float((y - model(x)).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
+    if cfg == "C5":
+        model.mlp_precision = "f32"                 # compare like with like: the oracle is not a bf16 model
+    n = 6
+    x = big.make_frames(n, seed=3)
+    xg = x.to(hip_device).requires_grad_(True)
+    G = torch.randn((n, big.out_dim()), generator=torch.Generator().manual_seed(4))
+    y = model(xg)
+    (y * G.to(hip_device)).sum().backward()
+    from molann_amd.ann import last_launch_info
+    assert "frames_wave_bwd_kernel" in last_launch_info(model.preprocessing_layer)
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    xx = x.double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    al = [a - 1 for a in big.align]
+    ref_x = mo.center_reference(torch.from_numpy(big.ref_xyz[al])).double()
+    want = mo.molann_forward(xx, [(t, [a - 1 for a in atoms]) for t, atoms in big.features], ws, bs,
+                             big.use_angle_value, al, ref_x)
+    (want * G.double()).sum().backward()
+    assert float((y.detach().cpu().double() - want.detach()).abs().max()) <= 1e-4
+    for got, ref in [(xg.grad, xx.grad)] + [(l.weight.grad, wt.grad) for l, wt in zip(lins, ws)]:
+        scale = max(1e-6, float(ref.abs().max()))
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-4 * scale, cfg
+    touched = set(al) | {a - 1 for _, atoms in big.features for a in atoms}
+    untouched = torch.tensor(sorted(set(range(big.n_atoms)) - touched)[:200])
+    assert float(xg.grad[:, untouched.to(hip_device)].abs().max()) == 0.0     # the row was zeroed, nothing else written
+
+
+def test_alignment_layer_gradient_on_large_frames(hip_device):
+    big = wl.get_workload("C4")
+    al_atoms = [a - 1 for a in big.align]
+    U5 = Universe(wl.synthetic_chain())
+    layer = AlignmentLayer(U5.atoms_by_number(big.align), U5.atoms).to(hip_device)
+    x = big.make_frames(3, seed=8)
+    xg = x.to(hip_device).requires_grad_(True)
+    G = torch.randn(x.shape, generator=torch.Generator().manual_seed(6))
+    (layer(xg) * G.to(hip_device)).sum().backward()
+    xx = x.double().requires_grad_(True)
+    ref_x = mo.center_reference(torch.from_numpy(big.ref_xyz[al_atoms])).double()
+    (mo.align_forward(xx, al_atoms, ref_x) * G.double()).sum().backward()
+    scale = float(xx.grad.abs().max())
+    assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * scale
 
 
 @pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.GELU])

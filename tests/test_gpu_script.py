@@ -101,3 +101,22 @@ def test_scripted_grad_x_only_under_frozen_parameters(hip_device):
     xe = x.detach().clone().requires_grad_(True)
     (ge,) = torch.autograd.grad(model(xe)[:, 0].sum(), [xe])
     assert torch.equal(gx, ge)
+
+
+def test_scripted_large_frame_model_is_differentiable(hip_device):
+    """A fused plan without a backward kernel (5000-atom frames): the operator composes the feature plan's
+    backward with the MLP as ATen ops, as the eager module does."""
+    w = wl.get_workload("C4")
+    model = workload_model(w, hip_device)
+    scripted = torch.jit.script(model)
+    x = w.make_frames(5, seed=2).to(hip_device)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = model(xa), scripted(xb)
+    assert float((ya - yb).detach().abs().max()) <= 1e-5 * max(1.0, float(ya.detach().abs().max()))
+    params = list(model.parameters())
+    ga = torch.autograd.grad(ya.sum(), [xa] + params)
+    gb = torch.autograd.grad(yb.sum(), [xb] + params)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+    with torch.no_grad():                                     # inference keeps the fused two-kernel path
+        assert torch.equal(scripted(x), model(x))
