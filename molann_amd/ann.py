@@ -10,11 +10,11 @@ in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
     create_sequential_nn(layer_dims, activation)                 ann.py:37-67
 
 There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 tensor that lives
-on a HIP device raises.  Gradients (w.r.t. x and the Linear parameters) come from a hand-written backward
-kernel for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32).  With a wider MLP
-(or ELU / GELU / Softplus) on small frames a forward under grad mode takes features and their gradient from
-the kernels and runs ``ann_layers`` as the torch module it is; on large frames (wave-per-frame kernel) a
-forward that would have to record gradients raises NotImplementedError: run it under ``torch.no_grad()``.
+on a HIP device raises.  Gradients (w.r.t. x and the Linear parameters) come from hand-written backward
+kernels: fused with the MLP for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32),
+features only on large frames (one wave per frame).  With an MLP outside the fused kernel (wider, ELU / GELU /
+Softplus, or any MLP on large frames) a forward under grad mode takes features and their gradient from the
+kernels and runs ``ann_layers`` as the torch module it is.
 """
 
 import torch

@@ -1417,6 +1417,10 @@ std::string jit_preamble(const JitSpec& j) {
     s += (debug_env().ablate & 64) ? "constexpr bool NO_RESTAGE = true;\n" : "constexpr bool NO_RESTAGE = false;\n";
     // diagnostic (bit 128): the whole next tile's LDS-DMA right after the register fill instead of in slices
     s += (debug_env().ablate & 128) ? "constexpr bool DMA_EARLY = true;\n" : "constexpr bool DMA_EARLY = false;\n";
+    // diagnostic (bit 256): every DMA re-reads the wave's first tile (L2-resident): the DMA mechanics without HBM
+    s += (debug_env().ablate & 256) ? "constexpr bool SAME_TILE = true;\n" : "constexpr bool SAME_TILE = false;\n";
+    // diagnostic (bit 512): the fused MLP's 16-byte output stores are (data-dependently) never executed
+    s += (debug_env().ablate & 512) ? "constexpr bool NO_STORES = true;\n" : "constexpr bool NO_STORES = false;\n";
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
@@ -1499,7 +1503,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         lds += (size_t)debug_env().lds_pad; // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
-        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
             unsigned long long* stamps = nullptr;
             if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
             struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
