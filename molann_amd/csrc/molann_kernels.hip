@@ -1185,6 +1185,8 @@ struct molann_plan {
     hipModule_t jit_mod;
     hipFunction_t jit_fn;
     int jit_nl;          // Linear layers fused into it (0: features only)
+    LaneGeom jit_geom;   // its own LDS geometry: the compact tile (touched 16-byte windows only) + staging columns
+    int jit_waves;       // waves per SIMD it was compiled for
     char jit_note[96];
     struct JitSpecBox* spec;   // what the specialised kernels are generated from (kept for the lazy backward build)
     hipModule_t bwd_mod;
@@ -1347,6 +1349,8 @@ std::string join_chunks(const char* const* chunks) {
 
 struct JitSpec { // what the specialised kernel is compiled for
     int n_inp, n_align, n_layers, act, d_feat, out_cols, wpb, lds_per_wave, fbuf_off;
+    int waves_per_eu = 2;             // occupancy the forward kernel is compiled for (amdgpu_waves_per_eu)
+    std::vector<int> win;             // compact staging: first dword of each 16-byte window copied per frame
     std::vector<int> slots;           // slot -> atom
     std::vector<ItemDev> items;       // atoms as slot indices
     std::vector<int> dims;
@@ -1356,6 +1360,25 @@ constexpr int JIT_MAX_ITEMS = 48, JIT_MAX_SLOTS = 32;
 } // namespace
 struct JitSpecBox { JitSpec j; std::vector<int> kp, jp; std::vector<long> woff; };
 namespace {
+
+// Compact staging (molann_lane_jit.inc): per frame only the 16-byte windows that hold a touched atom are copied
+// to LDS.  Greedy cover of the touched dwords (LDS-DMA gathers from any dword-aligned address); an odd number of
+// windows keeps the per-lane ds_read_b128 of the register fill conflict-free (frame stride = NW x 16 B).
+std::vector<int> compact_windows(const std::vector<int>& slot_atoms, int n_inp) {
+    const int frame_dw = 3 * n_inp;
+    std::vector<char> used(frame_dw, 0);
+    for (int a : slot_atoms)
+        for (int c = 0; c < 3; ++c) used[3 * a + c] = 1;
+    std::vector<int> win;
+    for (int d = 0; d < frame_dw; ++d) {
+        if (!used[d]) continue;
+        if (!win.empty() && d < win.back() + 4) continue; // covered by the last window
+        win.push_back(std::min(d, frame_dw - 4));      // never past the end of the frame (the last frame of x)
+    }
+    if (win.empty()) win.push_back(0);
+    if (win.size() % 2 == 0) win.push_back(win.back());
+    return win;
+}
 
 std::string jit_preamble(const JitSpec& j);
 
@@ -1411,6 +1434,14 @@ std::string jit_preamble(const JitSpec& j) {
     K("N_INP", j.n_inp); K("N_ALIGN", j.n_align); K("N_SLOTS", (int)j.slots.size()); K("N_ITEMS", (int)j.items.size());
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
+    K("WAVES_PER_EU", j.waves_per_eu);
+    {
+        std::vector<int> win = j.win.empty() ? std::vector<int>(1, 0) : j.win;
+        K("NWIN", (int)win.size());
+        s += "constexpr int WIN_START[] = {";
+        for (size_t i = 0; i < win.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", win[i]); s += b; }
+        s += "};\n";
+    }
     s += (debug_env().ablate & 32) ? "constexpr bool STAMPS = true;\n" : "constexpr bool STAMPS = false;\n";
     // diagnostic (MOLANN_DEBUG_ABLATE bit 64): every wave stages its first tile only and recomputes it for all its
     // tiles - the kernel's compute time without the HBM stream
@@ -1504,6 +1535,12 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
         if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+            const molann_plan::LaneGeom& jg = p->jit_geom;
+            const int jwpb = jg.wpb;
+            int jbpc = (int)(163840 / ((long)jwpb * jg.lds_per_wave));
+            jbpc = std::max(1, std::min(jbpc, std::max(1, 4 * p->jit_waves / jwpb)));
+            const int jgrid = grid_for(p, n_tiles, jwpb, jbpc);
+            const size_t jlds = (size_t)jwpb * jg.lds_per_wave + (size_t)debug_env().lds_pad;
             unsigned long long* stamps = nullptr;
             if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
             struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
@@ -1511,9 +1548,9 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
                                                                             a.out_vec4, stamps, p->d_ref};
             size_t ksz = sizeof(ka);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-            const hipError_t le = hipModuleLaunchKernel(p->jit_fn, grid, 1, 1, 64 * wpb, 1, 1, (unsigned)lds, stream, nullptr, cfg);
-            snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised) grid=%d block=%d lds=%zu",
-                     p->jit_nl, grid, 64 * wpb, lds);
+            const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, 64 * jwpb, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
+            snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised, %d waves/SIMD) grid=%d block=%d lds=%zu",
+                     p->jit_nl, p->jit_waves, jgrid, 64 * jwpb, jlds);
             return (int)le;
         }
         const bool regs = p->regs_mode;
@@ -1866,8 +1903,11 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         j.n_inp = d->n_inp; j.n_align = d->n_align; j.act = d->activation; j.d_feat = d_feat;
         j.n_layers = p->fused_mlp ? d->n_layers : 0;
         j.out_cols = p->fused_mlp ? p->out_dim : d_feat;
-        j.wpb = p->geom[0].wpb; j.lds_per_wave = p->geom[0].lds_per_wave; j.fbuf_off = p->geom[0].fbuf_off;
         j.slots = slots; j.items = items_slot;
+        // compact tile: only the 16-byte windows of a frame that hold a touched atom go to LDS, so more waves fit
+        j.win = compact_windows(slots, d->n_inp);
+        lane_geometry(p->jit_geom, 64 * 16 * (int)j.win.size(), cols_needed);
+        j.wpb = p->jit_geom.wpb; j.lds_per_wave = p->jit_geom.lds_per_wave; j.fbuf_off = p->jit_geom.fbuf_off;
         if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
         p->spec = new (std::nothrow) JitSpecBox();
         if (p->spec) {
@@ -1876,18 +1916,35 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             p->n_grad_params = 0;
             for (int l = 0; l < j.n_layers; ++l) p->n_grad_params += p->dims[l + 1] * p->dims[l] + p->dims[l + 1];
         }
-        std::vector<char> code;
-        std::string log;
-        const int rc = jit_compile(jit_source(j), code, log);
-        if (rc == 0 && hipModuleLoadData(&p->jit_mod, code.data()) == hipSuccess &&
-            hipModuleGetFunction(&p->jit_fn, p->jit_mod, "molann_lane_jit") == hipSuccess) {
-            p->jit_nl = j.n_layers;
-            snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %zu bytes", code.size());
-        } else {
-            p->jit_fn = nullptr;
-            snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
-            if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
+        // Two waves per SIMD.  With the compact tile the LDS would hold 12 waves per CU and the kernel compiles to
+        // 166 registers without scratch, but measured (C3) the third wave slows the arithmetic more (52 -> 65 us with
+        // the HBM stream removed) than it hides of the stream: 73.4 us against 71.3.  C2 is the same either way (41.5 /
+        // 41.9).  MOLANN_DEBUG_JIT_WAVES=3 builds the three-wave variant (it falls back if that build needs scratch).
+        int rc = -1;
+        const bool frame_ok = p->jit_geom.ok && 3 * d->n_inp >= 4;
+        const long lds_waves = frame_ok ? (long)j.wpb * (163840 / ((long)j.wpb * j.lds_per_wave)) : 0;
+        int waves0 = 2;
+        if (const char* e = getenv("MOLANN_DEBUG_JIT_WAVES")) waves0 = (atoi(e) >= 3 && lds_waves >= 12) ? 3 : 2;
+        for (int waves = waves0; frame_ok && waves >= 2 && !p->jit_fn; --waves) {
+            j.waves_per_eu = waves;
+            std::vector<char> code;
+            std::string log;
+            rc = jit_compile(jit_source(j), code, log);
+            hipModule_t mod = nullptr;
+            hipFunction_t fn = nullptr;
+            if (rc != 0 || hipModuleLoadData(&mod, code.data()) != hipSuccess ||
+                hipModuleGetFunction(&fn, mod, "molann_lane_jit") != hipSuccess) {
+                if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
+                if (mod) (void)hipModuleUnload(mod);
+                break;
+            }
+            int scratch = 0;
+            (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
+            if (scratch > 0 && waves > 2) { (void)hipModuleUnload(mod); continue; }
+            p->jit_mod = mod; p->jit_fn = fn; p->jit_nl = j.n_layers; p->jit_waves = waves;
+            snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %d waves/SIMD, %zu bytes", waves, code.size());
         }
+        if (!p->jit_fn) snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
     }
     // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
     snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
@@ -2198,9 +2255,11 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     j.n_layers = d->n_layers; j.out_cols = d->n_layers > 0 ? d->layer_dims[d->n_layers] : col;
     if (d->n_layers > 0) j.dims.assign(d->layer_dims, d->layer_dims + d->n_layers + 1);
     molann_plan::LaneGeom g;
-    lane_geometry(g, 64 * d->n_inp * 12, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
-    if (!g.ok) return MOLANN_E_UNSUPPORTED;
+    j.win = compact_windows(j.slots, d->n_inp);
+    lane_geometry(g, 64 * 16 * (int)j.win.size(), std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
+    if (!g.ok || 3 * d->n_inp < 4) return MOLANN_E_UNSUPPORTED;
     j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
+    j.waves_per_eu = 2;
     std::string src = jit_source(j);
     if (do_compile & 2) { // the backward kernel of the same plan
         JitSpecBox b;
