@@ -1350,6 +1350,7 @@ std::string join_chunks(const char* const* chunks) {
 struct JitSpec { // what the specialised kernel is compiled for
     int n_inp, n_align, n_layers, act, d_feat, out_cols, wpb, lds_per_wave, fbuf_off;
     int waves_per_eu = 2;             // occupancy the forward kernel is compiled for (amdgpu_waves_per_eu)
+    int nbuf = 1;                     // tile buffers per wave
     std::vector<int> win;             // compact staging: first dword of each 16-byte window copied per frame
     std::vector<int> slots;           // slot -> atom
     std::vector<ItemDev> items;       // atoms as slot indices
@@ -1378,6 +1379,24 @@ std::vector<int> compact_windows(const std::vector<int>& slot_atoms, int n_inp) 
     if (win.empty()) win.push_back(0);
     if (win.size() % 2 == 0) win.push_back(win.back());
     return win;
+}
+
+// LDS geometry of the specialised kernel: the compact tile (x2 when 8 waves per CU still fit: a wave then has the
+// next tile resident while the one after it is in flight) + the feature staging rows (the fused MLP reads only the
+// real D_FEAT rows; padded k's are zeros in registers).
+void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fallback_cols) {
+    const int tile = 64 * 16 * (int)j.win.size();
+    const int fb = ceil_to(std::max(1, staging_rows) * FB_STRIDE * 4, 16);
+    const long L2 = 2l * tile + fb;
+    const char* nb = getenv("MOLANN_DEBUG_JIT_NBUF"); // experiments: 2 = double-buffered tiles where they fit
+    if (nb && atoi(nb) == 2 && 2 * L2 <= 65536 && 8 * L2 <= 163840) { // blocks of 2 waves, 4 blocks per CU
+        g.wpb = 2; g.lds_per_wave = (int)L2; g.fbuf_off = 2 * tile; g.ok = 1;
+        j.nbuf = 2;
+    } else {
+        lane_geometry(g, tile, fallback_cols);
+        j.nbuf = 1;
+    }
+    j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
 }
 
 std::string jit_preamble(const JitSpec& j);
@@ -1434,7 +1453,7 @@ std::string jit_preamble(const JitSpec& j) {
     K("N_INP", j.n_inp); K("N_ALIGN", j.n_align); K("N_SLOTS", (int)j.slots.size()); K("N_ITEMS", (int)j.items.size());
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
-    K("WAVES_PER_EU", j.waves_per_eu);
+    K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
     {
         std::vector<int> win = j.win.empty() ? std::vector<int>(1, 0) : j.win;
         K("NWIN", (int)win.size());
@@ -1906,8 +1925,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         j.slots = slots; j.items = items_slot;
         // compact tile: only the 16-byte windows of a frame that hold a touched atom go to LDS, so more waves fit
         j.win = compact_windows(slots, d->n_inp);
-        lane_geometry(p->jit_geom, 64 * 16 * (int)j.win.size(), cols_needed);
-        j.wpb = p->jit_geom.wpb; j.lds_per_wave = p->jit_geom.lds_per_wave; j.fbuf_off = p->jit_geom.fbuf_off;
+        jit_geometry(j, p->jit_geom, p->fused_mlp ? d_feat : cols_needed, cols_needed);
         if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
         p->spec = new (std::nothrow) JitSpecBox();
         if (p->spec) {
@@ -2256,9 +2274,8 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     if (d->n_layers > 0) j.dims.assign(d->layer_dims, d->layer_dims + d->n_layers + 1);
     molann_plan::LaneGeom g;
     j.win = compact_windows(j.slots, d->n_inp);
-    lane_geometry(g, 64 * 16 * (int)j.win.size(), std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
+    jit_geometry(j, g, col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
     if (!g.ok || 3 * d->n_inp < 4) return MOLANN_E_UNSUPPORTED;
-    j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
     j.waves_per_eu = 2;
     std::string src = jit_source(j);
     if (do_compile & 2) { // the backward kernel of the same plan
