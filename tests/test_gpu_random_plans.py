@@ -1,0 +1,88 @@
+"""Randomly drawn plans (input group size, touched atoms, feature mix, alignment set, MLP) against the fp64 oracle:
+exercises the plan-specialised kernel's compact staging (which 16-byte windows of a frame are copied, windows
+clamped at the end of the frame, odd window counts, tiny frames) and its generic fallback on the same plans."""
+
+import numpy as np
+import pytest
+import torch
+
+from molann_amd import workloads as wl
+from molann_amd.ann import (AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn,
+                            last_launch_info)
+from molann_amd.atomgroup import Universe
+from molann_amd.feature import Feature
+from oracle import molann_oracle as mo
+
+pytestmark = pytest.mark.gpu
+NEED = {0: 3, 1: 2, 2: 4, 3: None}     # atoms per feature type (position: any number)
+
+
+def _draw(rng, case):
+    n_inp = int(rng.choice([1, 2, 3, 4, 5, 7, 12, 22, 31, 40]))
+    xyz = (rng.normal(size=(n_inp, 3)) * 2.5).astype(np.float32)
+    u = Universe(xyz)
+    feats, spec = [], []
+    for i in range(int(rng.integers(1, 7))):
+        t = int(rng.choice([0, 1, 2, 3]))
+        k = NEED[t] if NEED[t] is not None else int(rng.integers(1, min(n_inp, 4) + 1))
+        if k > n_inp:
+            t, k = (1, 2) if n_inp >= 2 else (3, 1)
+        # bias towards the ends of the frame (first / last atoms: clamped windows)
+        pool = np.arange(n_inp)
+        w = np.ones(n_inp); w[:2] += 2; w[-2:] += 3
+        atoms = rng.choice(pool, size=k, replace=False, p=w / w.sum()).tolist()
+        feats.append(Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])))
+        spec.append((t, atoms))
+    uav = bool(rng.integers(0, 2))
+    align = None
+    if n_inp >= 3 and case % 3 != 0:
+        align = sorted(rng.choice(np.arange(n_inp), size=int(rng.integers(3, min(n_inp, 8) + 1)), replace=False).tolist())
+    al = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms) if align is not None else None
+    pp = PreprocessingANN(al, FeatureLayer(feats, u.atoms, uav))
+    model = pp
+    if case % 2 == 0:
+        d = pp.output_dimension()
+        dims = [d] + [int(v) for v in rng.integers(2, 33, size=int(rng.integers(1, 3)))]
+        torch.manual_seed(case)
+        model = MolANN(pp, create_sequential_nn(dims))
+    return xyz, spec, uav, align, model
+
+
+def _oracle(model, x, spec, uav, align, xyz):
+    ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double() if align is not None else None
+    xd = x.double()
+    if isinstance(model, MolANN):
+        lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+        return mo.molann_forward(xd, spec, [l.weight.detach().cpu().double() for l in lins],
+                                 [l.bias.detach().cpu().double() for l in lins], uav, align, ref_x)
+    return mo.preprocessing_forward(xd, spec, uav, align, ref_x)
+
+
+@pytest.mark.parametrize("nojit", ["0", "1"], ids=["specialised", "generic"])
+def test_random_plans_match_oracle(nojit, hip_device, monkeypatch):
+    monkeypatch.setenv("MOLANN_NO_JIT", nojit)
+    rng = np.random.default_rng(2024)
+    kinds = set()
+    for case in range(60):
+        xyz, spec, uav, align, model = _draw(rng, case)
+        model = model.to(hip_device)
+        n = int(rng.choice([1, 63, 64, 130, 777]))
+        g = torch.Generator().manual_seed(case)
+        x = torch.from_numpy(xyz).unsqueeze(0) + 0.3 * torch.randn((n, xyz.shape[0], 3), generator=g)
+        if align is not None:                                        # random rigid motion per frame
+            q = torch.randn((n, 4), generator=g)
+            q = q / q.norm(dim=1, keepdim=True)
+            x = torch.einsum("nij,nkj->nki", wl.quaternion_to_matrix(q), x) + 2.0 * torch.randn((n, 1, 3), generator=g)
+        x = x.float().contiguous()
+        with torch.no_grad():
+            got = model(x.to(hip_device)).cpu()
+        want = _oracle(model, x, spec, uav, align, xyz)
+        info = last_launch_info(model if isinstance(model, MolANN) else model)
+        kinds.add(info.split("<")[0].split(" ")[0])
+        assert got.shape == want.shape, (case, info)
+        err = float((got.double() - want).abs().max())
+        # ill-conditioned alignment sets (3 random atoms may be nearly collinear) amplify fp32 rounding of
+        # position features; invariant features do not see the rotation at all
+        has_pos = any(t == 3 for t, _ in spec)
+        assert err <= (2e-4 if (has_pos and align is not None) else 2e-5), (case, err, info, spec, align)
+    assert ("molann_lane_jit" in kinds) == (nojit == "0"), kinds   # (a 1-atom frame has no 16-byte window: generic kernel)
