@@ -86,3 +86,51 @@ def test_random_plans_match_oracle(nojit, hip_device, monkeypatch):
         has_pos = any(t == 3 for t, _ in spec)
         assert err <= (2e-4 if (has_pos and align is not None) else 2e-5), (case, err, info, spec, align)
     assert ("molann_lane_jit" in kinds) == (nojit == "0"), kinds   # (a 1-atom frame has no 16-byte window: generic kernel)
+
+
+def test_random_plans_gradients(hip_device):
+    """The plan-specialised backward kernel on drawn plans: dL/dx (and parameter gradients) against autograd
+    through the fp64 oracle."""
+    rng = np.random.default_rng(77)
+    checked = 0
+    for case in range(40):
+        xyz, spec, uav, align, model = _draw(rng, case)
+        if xyz.shape[0] < 2:
+            continue
+        if align is not None:
+            if len(align) < 4:
+                continue
+            ref = xyz[align] - xyz[align].mean(0)
+            sv = np.linalg.svd(ref.T @ ref, compute_uv=False)
+            if sv[2] / sv[0] < 0.05:                                  # nearly planar reference: derivative ill-conditioned
+                continue
+        model = model.to(hip_device)
+        n = int(rng.choice([1, 65, 300]))
+        g = torch.Generator().manual_seed(1000 + case)
+        x = (torch.from_numpy(xyz).unsqueeze(0) + 0.15 * torch.randn((n, xyz.shape[0], 3), generator=g)).float().contiguous()
+        xg = x.to(hip_device).requires_grad_(True)
+        y = model(xg)
+        G = torch.randn(y.shape, generator=g)
+        (y * G.to(hip_device)).sum().backward()
+        xx = x.double().requires_grad_(True)
+        ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double() if align is not None else None
+        params = []
+        if isinstance(model, MolANN):
+            lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+            ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+            bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+            want = mo.molann_forward(xx, spec, ws, bs, uav, align, ref_x)
+            params = [(l.weight.grad, w.grad) for l, w in zip(lins, ws)] + [(l.bias.grad, b.grad) for l, b in zip(lins, bs)]
+        else:
+            want = mo.preprocessing_forward(xx, spec, uav, align, ref_x)
+        (want * G.double()).sum().backward()
+        if isinstance(model, MolANN):
+            params = [(l.weight.grad, w.grad) for l, w in zip(lins, ws)] + [(l.bias.grad, b.grad) for l, b in zip(lins, bs)]
+        # angle / dihedral VALUES have unbounded derivatives at the poles: skip frames sitting on one
+        if not torch.isfinite(xx.grad).all() or float(xx.grad.abs().max()) > 1e4:
+            continue
+        for got, ref in [(xg.grad, xx.grad)] + params:
+            scale = max(1e-6, float(ref.abs().max()))
+            assert float((got.cpu().double() - ref).abs().max()) <= 5e-4 * scale, (case, spec, align, uav)
+        checked += 1
+    assert checked >= 15, checked
