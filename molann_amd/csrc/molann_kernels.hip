@@ -1446,6 +1446,8 @@ std::string jit_source_bwd(const JitSpecBox& b, int lds_per_wave) {
     arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
     snprintf(t, sizeof(t), "constexpr int N_PARAMS = %ld;\n", g);
     s += t;
+    // diagnostic (MOLANN_DEBUG_ABLATE bit 1024): constants instead of the scalar weight loads (results are wrong)
+    s += (debug_env().ablate & 1024) ? "constexpr bool FAKE_W = true;\n" : "constexpr bool FAKE_W = false;\n";
     s += "#line 1 \"molann_lane_bwd.inc\"\n";
     s += join_chunks(k_src_molann_lane_bwd_inc);
     return s;
@@ -1558,7 +1560,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         lds += (size_t)debug_env().lds_pad; // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
-        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
             const molann_plan::LaneGeom& jg = p->jit_geom;
             const int jwpb = jg.wpb;
             int jbpc = (int)(163840 / ((long)jwpb * jg.lds_per_wave));
