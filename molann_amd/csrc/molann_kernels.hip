@@ -1461,6 +1461,10 @@ std::string jit_preamble(const JitSpec& j) {
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
     K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
+    {   // cache policy of the x stream's LDS-DMA (gfx940+ CPol bits: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+        const char* e = getenv("MOLANN_DEBUG_DMA_AUX");
+        K("DMA_AUX", e ? atoi(e) : 0);
+    }
     {
         std::vector<int> win = j.win.empty() ? std::vector<int>(1, 0) : j.win;
         K("NWIN", (int)win.size());
