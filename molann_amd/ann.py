@@ -560,12 +560,15 @@ class MolANN(_PlanOwner, torch.nn.Module):
             w0 = st["linears"][0].weight
             if w0.device != x.device or w0.dtype != torch.float32:
                 raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))
-            entry = st["entry"]()
-            with torch.cuda.device(x.device):
-                if al is not None:
-                    entry.sync_ref(_device_buffer(al.ref_x, x))
-                entry.sync_mlp(st["linears"])
-                if entry.plan.supports_backward():
+            if st.get("fused_bwd") is None:           # asked once: the answer is a property of the plan
+                with torch.cuda.device(x.device):
+                    st["fused_bwd"] = bool(st["entry"]().plan.supports_backward())
+            if st["fused_bwd"]:
+                entry = st["entry"]()
+                with torch.cuda.device(x.device):
+                    if al is not None:
+                        entry.sync_ref(_device_buffer(al.ref_x, x))
+                    entry.sync_mlp(st["linears"])
                     return _PlanFunction.apply(x, entry, True, *st["params"])
             # No fused backward kernel (MLP wider than 32 / ELU, GELU, Softplus).  Training still works when the
             # preprocessing has one (small frames): features and their gradient from the HIP kernels, the MLP and
