@@ -1461,6 +1461,12 @@ std::string jit_preamble(const JitSpec& j) {
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
     K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
+    {   // Opt-in, never used for a reported number: a plan whose items are all invariant under rigid motion produces the
+        // same output with or without its alignment; MOLANN_ELIDE_INVARIANT_ALIGNMENT=1 (read at plan creation) drops
+        // the (then dead) Kabsch from the specialised kernel.  Default: the alignment is computed, as the reference does.
+        const char* e = getenv("MOLANN_ELIDE_INVARIANT_ALIGNMENT");
+        s += (e && e[0] == '1') ? "constexpr bool ELIDE_ALIGN = true;\n" : "constexpr bool ELIDE_ALIGN = false;\n";
+    }
     {   // cache policy of the x stream's LDS-DMA (gfx940+ CPol bits: 1 = sc0, 2 = nt, 16 = sc1); experiments only
         const char* e = getenv("MOLANN_DEBUG_DMA_AUX");
         K("DMA_AUX", e ? atoi(e) : 0);
