@@ -134,3 +134,31 @@ def test_random_plans_gradients(hip_device):
             assert float((got.cpu().double() - ref).abs().max()) <= 5e-4 * scale, (case, spec, align, uav)
         checked += 1
     assert checked >= 15, checked
+
+
+@pytest.mark.parametrize("n_inp", [48, 64, 85, 86, 100, 150, 213, 300, 1000])
+def test_frame_sizes_across_the_lane_wave_boundary(n_inp, hip_device):
+    """Input groups around the size where plans move from the lane-per-frame to the wave-per-frame kernel."""
+    rng = np.random.default_rng(n_inp)
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    u = Universe(xyz)
+    spec = [(2, [0, 1, 2, 3]), (1, [n_inp - 2, n_inp - 1]), (0, [n_inp // 2, n_inp // 2 + 1, n_inp // 2 + 3]),
+            (3, [n_inp - 1, 0]), (2, [n_inp - 4, n_inp - 3, n_inp - 2, n_inp - 1])]
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])) for i, (t, atoms) in enumerate(spec)]
+    align = sorted(rng.choice(np.arange(n_inp), size=min(n_inp, 24), replace=False).tolist())
+    pp = PreprocessingANN(AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms), FeatureLayer(feats, u.atoms, False))
+    torch.manual_seed(n_inp)
+    model = MolANN(pp, create_sequential_nn([pp.output_dimension(), 16, 4])).to(hip_device)
+    n = 193
+    g = torch.Generator().manual_seed(n_inp)
+    x = torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)
+    q = torch.randn((n, 4), generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    x = (torch.einsum("nij,nkj->nki", wl.quaternion_to_matrix(q), x) + torch.randn((n, 1, 3), generator=g)).float().contiguous()
+    with torch.no_grad():
+        got = model(x.to(hip_device)).cpu()
+        aligned = pp.align_layer(x.to(hip_device)).cpu()
+    want = _oracle(model, x, spec, False, align, xyz)
+    assert float((got.double() - want).abs().max()) <= 1e-4, last_launch_info(model)   # position items behind a 24-atom fit
+    ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
+    assert float((aligned.double() - mo.align_forward(x.double(), align, ref_x)).abs().max()) <= 1e-4
