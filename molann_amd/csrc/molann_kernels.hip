@@ -1558,7 +1558,30 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
     const int out_cols = mode == 1 ? 0 : (with_mlp ? p->out_dim : p->d_feat);
     PreArgs a;
     fill_pre_args(p, a, n_frames, mode, out_cols, with_mlp, x, out);
+    // the plan-specialised lane kernel first: it serves every plan it was built for, including few-atom plans on
+    // frames too large for the ahead-of-time lane kernel's dense tile
+    if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+        const molann_plan::LaneGeom& jg = p->jit_geom;
+        const long n_tiles = (n_frames + 63) / 64;
+        const int jwpb = jg.wpb;
+        int jbpc = (int)(163840 / ((long)jwpb * jg.lds_per_wave));
+        jbpc = std::max(1, std::min(jbpc, std::max(1, 4 * p->jit_waves / jwpb)));
+        const int jgrid = grid_for(p, n_tiles, jwpb, jbpc);
+        const size_t jlds = (size_t)jwpb * jg.lds_per_wave + (size_t)debug_env().lds_pad;
+        unsigned long long* stamps = nullptr;
+        if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
+        struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
+                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
+                                                                        a.out_vec4, stamps, p->d_ref};
+        size_t ksz = sizeof(ka);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+        const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, 64 * jwpb, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
+        snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised, %d waves/SIMD) grid=%d block=%d lds=%zu",
+                 p->jit_nl, p->jit_waves, jgrid, 64 * jwpb, jlds);
+        return (int)le;
+    }
     const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
+    if (mode == 0 && p->family == 0 && !g.ok) return MOLANN_E_UNSUPPORTED; // lane plan by hipRTC only, and a diagnostic switch excluded it
     if (g.ok) {
         const int wpb = g.wpb;
         const long n_tiles = (n_frames + 63) / 64;
@@ -1570,25 +1593,6 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         lds += (size_t)debug_env().lds_pad; // diagnostic: lower the occupancy
         const dim3 block(64 * wpb);
         const int w = with_mlp ? p->n_layers : 0;
-        if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
-            const molann_plan::LaneGeom& jg = p->jit_geom;
-            const int jwpb = jg.wpb;
-            int jbpc = (int)(163840 / ((long)jwpb * jg.lds_per_wave));
-            jbpc = std::max(1, std::min(jbpc, std::max(1, 4 * p->jit_waves / jwpb)));
-            const int jgrid = grid_for(p, n_tiles, jwpb, jbpc);
-            const size_t jlds = (size_t)jwpb * jg.lds_per_wave + (size_t)debug_env().lds_pad;
-            unsigned long long* stamps = nullptr;
-            if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
-            struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
-                     unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
-                                                                            a.out_vec4, stamps, p->d_ref};
-            size_t ksz = sizeof(ka);
-            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-            const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, 64 * jwpb, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
-            snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised, %d waves/SIMD) grid=%d block=%d lds=%zu",
-                     p->jit_nl, p->jit_waves, jgrid, 64 * jwpb, jlds);
-            return (int)le;
-        }
         const bool regs = p->regs_mode;
 #define LAUNCH_LANE(W, M)                                                                                         \
     hipLaunchKernelGGL((frames_lane_kernel<W, M>), dim3(grid), block, lds, stream, x, out, p->d_align_idx, p->d_ref, \
@@ -1788,8 +1792,16 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     if (p->n_items > 0 && lane_tables_fit && cols_needed <= LANE_MAX_COLS)
         lane_geometry(p->geom[0], 64 * d->n_inp * 12, cols_needed);
     if (d->n_align > 0 && lane_tables_fit) lane_geometry(p->geom[1], 64 * d->n_inp * 12, 1);
+    // The plan-specialised lane kernel stages only the touched 16-byte windows of a frame, so its tile does not grow
+    // with n_inp: a plan that touches few atoms (<= 32) of a LARGE frame is a lane-per-frame plan too, as long as
+    // hipRTC is there to build it (the ahead-of-time lane kernel needs the dense tile and cannot serve it).
+    const char* nojit_env = getenv("MOLANN_NO_JIT");
+    const bool jit_possible = rtc_api()->ok && !(nojit_env && nojit_env[0] == '1') && p->n_items > 0 &&
+                              p->n_items <= JIT_MAX_ITEMS && p->n_slots <= JIT_MAX_SLOTS && align_is_prefix &&
+                              cols_needed <= LANE_MAX_COLS && 3 * d->n_inp >= 4;
+    const bool lane_by_jit_only = jit_possible && !p->geom[0].ok;
     // the family names the kernel that serves the plan's main product (features if it has any)
-    p->family = (p->n_items > 0 ? p->geom[0].ok : p->geom[1].ok) ? 0 : 1;
+    p->family = (p->n_items > 0 ? (p->geom[0].ok || lane_by_jit_only) : p->geom[1].ok) ? 0 : 1;
     p->fused_mlp = (p->family == 0) && small_mlp && d->n_features > 0;
 
     // ---- device blob ----------------------------------------------------------------------------
@@ -1932,9 +1944,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     }
     // ---- plan-specialised lane kernel --------------------------------------------------------------
     snprintf(p->jit_note, sizeof(p->jit_note), "jit: not applicable");
-    const char* nojit = getenv("MOLANN_NO_JIT");
-    if (p->geom[0].ok && align_is_prefix && p->n_items <= JIT_MAX_ITEMS && p->n_slots <= JIT_MAX_SLOTS &&
-        !(nojit && nojit[0] == '1')) {
+    const char* nojit = nojit_env;
+    if (jit_possible) {
         JitSpec j;
         j.n_inp = d->n_inp; j.n_align = d->n_align; j.act = d->activation; j.d_feat = d_feat;
         j.n_layers = p->fused_mlp ? d->n_layers : 0;
@@ -1980,6 +1991,10 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %d waves/SIMD, %zu bytes", waves, code.size());
         }
         if (!p->jit_fn) snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
+    }
+    if (lane_by_jit_only && !p->jit_fn) { // hipRTC is present but the build failed: there is no other lane kernel for this plan
+        molann_plan_destroy(p);
+        return MOLANN_E_UNSUPPORTED;
     }
     // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
     snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
@@ -2167,7 +2182,7 @@ int molann_plan_grad_params_size(const molann_plan* p) { return p ? p->n_grad_pa
 
 int molann_plan_supports_backward(const molann_plan* p) {
     if (!p) return MOLANN_E_NULL;
-    if (!p->geom[0].ok && p->n_items > 0 && p->n_layers == 0) return 1; // large frames, features only: frames_wave_bwd_kernel
+    if (!p->geom[0].ok) return (p->n_items > 0 && p->n_layers == 0) ? 1 : 0; // large frames: features only (frames_wave_bwd_kernel)
     if (!p->spec || p->n_items <= 0 || p->bwd_state < 0 || !rtc_api()->ok) return 0;
     if (p->n_layers > 0 && !p->fused_mlp) return 0;
     const int act = p->act;

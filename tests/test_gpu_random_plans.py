@@ -162,3 +162,42 @@ def test_frame_sizes_across_the_lane_wave_boundary(n_inp, hip_device):
     assert float((got.double() - want).abs().max()) <= 1e-4, last_launch_info(model)   # position items behind a 24-atom fit
     ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
     assert float((aligned.double() - mo.align_forward(x.double(), align, ref_x)).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("n_inp", [100, 1000, 5000])
+def test_few_touched_atoms_of_a_large_frame_take_the_lane_kernel(n_inp, hip_device, monkeypatch):
+    """The specialised lane kernel stages only touched windows, so its tile does not grow with the frame: a plan
+    touching <= 32 atoms of a 5000-atom frame is a lane-per-frame plan (and a wave-per-frame one without hipRTC)."""
+    rng = np.random.default_rng(n_inp)
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    u = Universe(xyz)
+    spec = [(2, [0, 1, 2, 3]), (1, [n_inp - 2, n_inp - 1]), (0, [n_inp // 2, n_inp // 2 + 1, n_inp // 2 + 3]),
+            (3, [n_inp - 1, 7]), (2, [n_inp - 4, n_inp - 3, n_inp - 2, n_inp - 1])]
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])) for i, (t, atoms) in enumerate(spec)]
+    align = sorted(rng.choice(np.arange(n_inp), size=8, replace=False).tolist())
+    n = 300
+    g = torch.Generator().manual_seed(n_inp)
+    x = (torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)).float().contiguous()
+    outs = {}
+    for nojit in ("0", "1"):
+        monkeypatch.setenv("MOLANN_NO_JIT", nojit)
+        pp = PreprocessingANN(AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms), FeatureLayer(feats, u.atoms, False))
+        torch.manual_seed(n_inp)
+        model = MolANN(pp, create_sequential_nn([pp.output_dimension(), 16, 4])).to(hip_device)
+        with torch.no_grad():
+            outs[nojit] = model(x.to(hip_device)).cpu()
+        info = last_launch_info(model)
+        assert ("molann_lane_jit" in info) == (nojit == "0"), info
+        want = _oracle(model, x, spec, False, align, xyz)
+        assert float((outs[nojit].double() - want).abs().max()) <= 1e-4, info
+    # gradients w.r.t. x: the wave-per-frame backward serves the feature plan, the MLP is torch's (composition)
+    monkeypatch.setenv("MOLANN_NO_JIT", "0")
+    pp = PreprocessingANN(AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms), FeatureLayer(feats, u.atoms, False))
+    torch.manual_seed(n_inp)
+    model = MolANN(pp, create_sequential_nn([pp.output_dimension(), 16, 4])).to(hip_device)
+    xg = x[:40].to(hip_device).requires_grad_(True)
+    model(xg).sum().backward()
+    xx = x[:40].double().requires_grad_(True)
+    _oracle(model, xx, spec, False, align, xyz).sum().backward()
+    scale = float(xx.grad.abs().max())
+    assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 5e-4 * scale
