@@ -1796,9 +1796,17 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     // with n_inp: a plan that touches few atoms (<= 32) of a LARGE frame is a lane-per-frame plan too, as long as
     // hipRTC is there to build it (the ahead-of-time lane kernel needs the dense tile and cannot serve it).
     const char* nojit_env = getenv("MOLANN_NO_JIT");
-    const bool jit_possible = rtc_api()->ok && !(nojit_env && nojit_env[0] == '1') && p->n_items > 0 &&
-                              p->n_items <= JIT_MAX_ITEMS && p->n_slots <= JIT_MAX_SLOTS && align_is_prefix &&
-                              cols_needed <= LANE_MAX_COLS && 3 * d->n_inp >= 4;
+    bool jit_possible = rtc_api()->ok && !(nojit_env && nojit_env[0] == '1') && p->n_items > 0 &&
+                        p->n_items <= JIT_MAX_ITEMS && p->n_slots <= JIT_MAX_SLOTS && align_is_prefix &&
+                        cols_needed <= LANE_MAX_COLS && 3 * d->n_inp >= 4;
+    if (jit_possible) { // and its LDS geometry (compact tile + staging rows) must leave room for >= 4 waves per CU
+        JitSpec probe;
+        probe.win = compact_windows(slots, d->n_inp);
+        molann_plan::LaneGeom pg;
+        memset(&pg, 0, sizeof(pg));
+        jit_geometry(probe, pg, (small_mlp && d->n_features > 0) ? d_feat : cols_needed, cols_needed);
+        jit_possible = pg.ok != 0;
+    }
     const bool lane_by_jit_only = jit_possible && !p->geom[0].ok;
     // the family names the kernel that serves the plan's main product (features if it has any)
     p->family = (p->n_items > 0 ? (p->geom[0].ok || lane_by_jit_only) : p->geom[1].ok) ? 0 : 1;
@@ -1992,9 +2000,12 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         }
         if (!p->jit_fn) snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
     }
-    if (lane_by_jit_only && !p->jit_fn) { // hipRTC is present but the build failed: there is no other lane kernel for this plan
-        molann_plan_destroy(p);
-        return MOLANN_E_UNSUPPORTED;
+    if (lane_by_jit_only && !p->jit_fn) { // hipRTC is present but the build failed: no other lane kernel for this plan
+        if (p->fused_mlp) { // its MLP was planned into that kernel: nothing to fall back to
+            molann_plan_destroy(p);
+            return MOLANN_E_UNSUPPORTED;
+        }
+        p->family = 1; // features from the wave-per-frame kernel
     }
     // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
     snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
