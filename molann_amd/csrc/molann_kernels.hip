@@ -990,7 +990,8 @@ struct PackArgs {
 // k = 16(ks>>2) + 4q + (ks&3) for the following layers; then the bias fragments b_l[16ub + 4q + r].
 __global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
     const int NL = p.n_layers;
-    const int total = NL * 1024 + NL * 512;
+    const int base = NL * 1024 + NL * 512;
+    const int total = base + 1024; // + layer 0's k-steps 8..15 (feature dims 33..64, specialised kernel only)
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int lane = e & 63, i = lane & 15, q = lane >> 4;
         float v = 0.f;
@@ -1000,11 +1001,17 @@ __global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
             const int j = 16 * ub + i;
             const int k = l == 0 ? 4 * ks + q : 16 * (ks >> 2) + 4 * q + (ks & 3);
             if (j < J && k < K) v = p.W[l][(long)j * K + k];
-        } else {
+        } else if (e < base) {
             const int f = e - NL * 1024;
             const int r = (f >> 6) & 3, ub = (f >> 8) & 1, l = f >> 9;
             const int j = 16 * ub + 4 * q + r;
             if (j < p.dims[l + 1]) v = p.b[l][j];
+        } else {
+            const int f = e - base;
+            const int ks = 8 + ((f >> 6) & 7), ub = (f >> 9) & 1;
+            const int K = p.dims[0], J = p.dims[1];
+            const int j = 16 * ub + i, k = 4 * ks + q;
+            if (j < J && k < K) v = p.W[0][(long)j * K + k];
         }
         dst[e] = v;
     }
@@ -1192,6 +1199,7 @@ struct molann_plan {
     int jit_nl;          // Linear layers fused into it (0: features only)
     LaneGeom jit_geom;   // its own LDS geometry: the compact tile (touched 16-byte windows only) + staging columns
     int jit_waves;       // waves per SIMD it was compiled for
+    bool jit_only;       // no ahead-of-time kernel serves this plan's fused forward (large frame / 33..64 features)
     char jit_note[96];
     struct JitSpecBox* spec;   // what the specialised kernels are generated from (kept for the lazy backward build)
     hipModule_t bwd_mod;
@@ -1362,7 +1370,7 @@ struct JitSpec { // what the specialised kernel is compiled for
     std::vector<int> dims;
 };
 
-constexpr int JIT_MAX_ITEMS = 48, JIT_MAX_SLOTS = 32;
+constexpr int JIT_MAX_ITEMS = 128, JIT_MAX_SLOTS = 32;
 } // namespace
 struct JitSpecBox { JitSpec j; std::vector<int> kp, jp; std::vector<long> woff; };
 namespace {
@@ -1581,7 +1589,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         return (int)le;
     }
     const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
-    if (mode == 0 && p->family == 0 && !g.ok) return MOLANN_E_UNSUPPORTED; // lane plan by hipRTC only, and a diagnostic switch excluded it
+    if (mode == 0 && p->jit_only && (with_mlp || !g.ok)) return MOLANN_E_UNSUPPORTED; // served by the specialised kernel only, and a diagnostic switch excluded it
     if (g.ok) {
         const int wpb = g.wpb;
         const long n_tiles = (n_frames + 63) / 64;
@@ -1771,6 +1779,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
                            d->activation != MOLANN_ACT_GELU;
     const bool small_mlp = d->n_layers > 0 && d->n_layers <= LANE_MLP_MAX_LAYERS && max_w <= LANE_MLP_MAX_WIDTH &&
                            d_feat <= LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
+    // feature dims 33..64 in front of such an MLP: fused too, by the plan-specialised kernel only (16 k-steps in layer 0)
+    const bool wide_in_mlp = !small_mlp && d->n_layers > 0 && d->n_layers <= LANE_MLP_MAX_LAYERS && max_w <= LANE_MLP_MAX_WIDTH &&
+                             d_feat <= 2 * LANE_MLP_MAX_WIDTH && d->mlp_precision == MOLANN_MLP_F32 && cheap_act;
     const int cols_needed = std::max(1, small_mlp ? ceil_to(d_feat, 4) : d_feat);
     // touched atoms -> slots in first-use order: align atoms, then the feature table's atoms
     std::vector<int> slot_of(d->n_inp, -1), slots;
@@ -1804,13 +1815,15 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         probe.win = compact_windows(slots, d->n_inp);
         molann_plan::LaneGeom pg;
         memset(&pg, 0, sizeof(pg));
-        jit_geometry(probe, pg, (small_mlp && d->n_features > 0) ? d_feat : cols_needed, cols_needed);
+        jit_geometry(probe, pg, ((small_mlp || wide_in_mlp) && d->n_features > 0) ? d_feat : cols_needed, cols_needed);
         jit_possible = pg.ok != 0;
     }
     const bool lane_by_jit_only = jit_possible && !p->geom[0].ok;
+    const bool fused_by_jit_only = jit_possible && wide_in_mlp && d->n_features > 0;
     // the family names the kernel that serves the plan's main product (features if it has any)
     p->family = (p->n_items > 0 ? (p->geom[0].ok || lane_by_jit_only) : p->geom[1].ok) ? 0 : 1;
-    p->fused_mlp = (p->family == 0) && small_mlp && d->n_features > 0;
+    p->fused_mlp = ((p->family == 0) && small_mlp && d->n_features > 0) || fused_by_jit_only;
+    p->jit_only = lane_by_jit_only || fused_by_jit_only;
 
     // ---- device blob ----------------------------------------------------------------------------
     size_t off = 0;
@@ -1823,7 +1836,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const size_t o_slots = carve(sizeof(int) * std::max<size_t>(1, slots.size()));
 
     size_t lane_floats = 0;
-    if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512);
+    if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512) + 1024;
     const size_t o_wlane = carve(sizeof(float) * std::max<size_t>(1, lane_floats));
     size_t mfma_bytes = 0;
     const bool bf16 = d->mlp_precision == MOLANN_MLP_BF16;
@@ -2000,12 +2013,13 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         }
         if (!p->jit_fn) snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
     }
-    if (lane_by_jit_only && !p->jit_fn) { // hipRTC is present but the build failed: no other lane kernel for this plan
+    if (p->jit_only && !p->jit_fn) { // hipRTC is present but the build failed: no other lane kernel for this plan
         if (p->fused_mlp) { // its MLP was planned into that kernel: nothing to fall back to
             molann_plan_destroy(p);
             return MOLANN_E_UNSUPPORTED;
         }
-        p->family = 1; // features from the wave-per-frame kernel
+        p->jit_only = false;
+        if (!p->geom[0].ok) p->family = 1; // features from the wave-per-frame kernel
     }
     // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
     snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
@@ -2195,7 +2209,7 @@ int molann_plan_supports_backward(const molann_plan* p) {
     if (!p) return MOLANN_E_NULL;
     if (!p->geom[0].ok) return (p->n_items > 0 && p->n_layers == 0) ? 1 : 0; // large frames: features only (frames_wave_bwd_kernel)
     if (!p->spec || p->n_items <= 0 || p->bwd_state < 0 || !rtc_api()->ok) return 0;
-    if (p->n_layers > 0 && !p->fused_mlp) return 0;
+    if (p->n_layers > 0 && (!p->fused_mlp || p->d_feat > LANE_MLP_MAX_WIDTH)) return 0;
     const int act = p->act;
     if (p->n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return 0;
     return 1;
@@ -2223,7 +2237,7 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
     if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
     const int act = p->act;
     if (p->spec->j.n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return MOLANN_E_UNSUPPORTED;
-    if (p->n_layers > 0 && !p->fused_mlp) return MOLANN_E_UNSUPPORTED; // wide MLPs: not yet
+    if (p->n_layers > 0 && (!p->fused_mlp || p->d_feat > LANE_MLP_MAX_WIDTH)) return MOLANN_E_UNSUPPORTED; // wide MLPs / > 32 features
     if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
     molann_plan::LaneGeom g;
     lane_geometry(g, std::max(64 * p->n_inp * 12, 64 * 68 * 4), 1); // frame tile, reused as the [unit][frame] scratch

@@ -201,3 +201,34 @@ def test_few_touched_atoms_of_a_large_frame_take_the_lane_kernel(n_inp, hip_devi
     _oracle(model, xx, spec, False, align, xyz).sum().backward()
     scale = float(xx.grad.abs().max())
     assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 5e-4 * scale
+
+
+@pytest.mark.parametrize("n_feat", [33, 40, 49])
+def test_mlp_behind_33_to_64_features_is_fused(n_feat, hip_device):
+    """Feature dimensions 33..64 in front of a narrow MLP: 16 k-steps in layer 0 of the specialised kernel's MFMA
+    MLP (the ahead-of-time kernel stops at 32 and leaves such an MLP to mlp_mfma_kernel)."""
+    import itertools
+    u = Universe(wl.ALA_DIPEPTIDE_XYZ)
+    heavy = [2, 5, 6, 7, 9, 11, 15, 16, 17, 19]
+    pairs = list(itertools.combinations(heavy, 2))[:45]
+    dihs = [(5, 7, 9, 15), (7, 9, 15, 17), (2, 5, 7, 9), (9, 15, 17, 19)]
+    spec = [(1, [a - 1 for a in p]) for p in pairs] + [(2, [a - 1 for a in d]) for d in dihs]
+    spec = spec[:n_feat] if n_feat <= 45 else spec
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])) for i, (t, atoms) in enumerate(spec)]
+    align = [1, 4, 6, 8, 14, 16, 18]
+    pp = PreprocessingANN(AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms), FeatureLayer(feats, u.atoms, False))
+    torch.manual_seed(n_feat)
+    model = MolANN(pp, create_sequential_nn([pp.output_dimension(), 30, 30, 2])).to(hip_device)
+    w = wl.get_workload("C3")
+    x = w.make_frames(1000, seed=n_feat)
+    with torch.no_grad():
+        got = model(x.to(hip_device)).cpu()
+    info = last_launch_info(model)
+    assert "molann_lane_jit<NL=3>" in info, info
+    want = _oracle(model, x, spec, False, align, wl.ALA_DIPEPTIDE_XYZ.astype(np.float32))
+    assert float((got.double() - want).abs().max()) <= 2e-5, info
+    xg = x[:100].to(hip_device).requires_grad_(True)            # no fused backward at this width: composition
+    model(xg).sum().backward()
+    xx = x[:100].double().requires_grad_(True)
+    _oracle(model, xx, spec, False, align, wl.ALA_DIPEPTIDE_XYZ.astype(np.float32)).sum().backward()
+    assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 5e-4 * float(xx.grad.abs().max())
