@@ -1041,14 +1041,17 @@ __global__ void pack_mfma_kernel(void* __restrict__ dst_v, PackArgs p) {
 // ---- chain MLP (molann_mlp_jit.inc): host mirror of the kernel text's constexpr geometry --------------------
 struct ChainGeom {
     int nl;
+    int bf16; // 1: bf16 MFMA 16x16x32 (32 k's per fragment, chunks of two 16-unit blocks); 0: fp32 MFMA 16x16x4 (16, one)
     int dims[MOLANN_MAX_LAYERS + 1];
+    int cb() const { return bf16 ? 2 : 1; }
+    int kw() const { return bf16 ? 32 : 16; }
     int ub(int l) const { return (dims[l + 1] + 15) / 16; }
-    int ubp(int l) const { return (ub(l) + 1) & ~1; }
-    int ks(int l) const { return l == 0 ? (dims[0] + 31) / 32 : ubp(l - 1) / 2; }
+    int ubp(int l) const { return (ub(l) + cb() - 1) / cb() * cb(); }
+    int ks(int l) const { return l == 0 ? (dims[0] + kw() - 1) / kw() : ubp(l - 1) / cb(); }
     int npair() const { return (nl + 1) / 2; }
     bool has_c(int p) const { return 2 * p + 1 < nl; }
-    int nchunk(int p) const { return ubp(2 * p) / 2; }
-    int slab_frags(int p) const { return 2 * ks(2 * p) + (has_c(p) ? ub(2 * p + 1) : 0); }
+    int nchunk(int p) const { return ubp(2 * p) / cb(); }
+    int slab_frags(int p) const { return cb() * ks(2 * p) + (has_c(p) ? ub(2 * p + 1) : 0); }
     int slab_max() const { int m = 0; for (int p = 0; p < npair(); ++p) m = std::max(m, slab_frags(p)); return m; }
     long total_frags() const { long s = 0; for (int p = 0; p < npair(); ++p) s += (long)nchunk(p) * slab_frags(p); return s; }
     int bias_off(int l) const { int s = 0; for (int i = 0; i < l; ++i) s += 16 * ubp(i); return s; }
@@ -1057,8 +1060,8 @@ struct ChainGeom {
     int regs_per_fb() const {
         int m = 0;
         for (int p = 0; p < npair(); ++p) {
-            const int ksin = ks(2 * p), ubc = has_c(p) ? ub(2 * p + 1) : 0, ksn = has_c(p) ? ubp(2 * p + 1) / 2 : 0;
-            m = std::max(m, 4 * (ksin + ubc + 2 + (ksn + 1) / 2));
+            const int ksin = ks(2 * p), ubc = has_c(p) ? ub(2 * p + 1) : 0, ksn = has_c(p) ? ubp(2 * p + 1) / cb() : 0;
+            m = std::max(m, 4 * (ksin + ubc + cb() + (ksn + 1) / 2));
         }
         return m;
     }
@@ -1068,7 +1071,7 @@ struct ChainPackArgs {
     const float* W[MOLANN_MAX_LAYERS];
     const float* b[MOLANN_MAX_LAYERS];
     int dims[MOLANN_MAX_LAYERS + 1];
-    int n_layers, npair;
+    int n_layers, npair, bf16;
     int pair_start[MOLANN_MAX_LAYERS / 2 + 1]; // first fragment of pair p (last entry: total)
     int slab_frags[MOLANN_MAX_LAYERS / 2];
     int ks_in[MOLANN_MAX_LAYERS / 2];
@@ -1088,19 +1091,30 @@ __global__ void pack_chain_kernel(unsigned char* __restrict__ dst, ChainPackArgs
         int p = 0;
         while (p + 1 < a.npair && F >= a.pair_start[p + 1]) ++p;
         const int rel = F - a.pair_start[p], c = rel / a.slab_frags[p], f = rel % a.slab_frags[p];
+        const int cb = a.bf16 ? 2 : 1;
         int l, ub, ks;
-        if (f < 2 * a.ks_in[p]) { l = 2 * p; ks = f >> 1; ub = 2 * c + (f & 1); }
-        else { l = 2 * p + 1; ub = f - 2 * a.ks_in[p]; ks = c; }
+        if (f < cb * a.ks_in[p]) { l = 2 * p; ks = f / cb; ub = cb * c + f % cb; }
+        else { l = 2 * p + 1; ub = f - cb * a.ks_in[p]; ks = c; }
         const int K = a.dims[l], J = a.dims[l + 1], j = 16 * ub + i;
-        unsigned short v[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = l == 0 ? 32 * ks + 8 * q + s : 16 * (2 * ks + (s >> 2)) + 4 * q + (s & 3);
-            v[s] = f2bf((j < J && k < K) ? a.W[l][(long)j * K + k] : 0.f);
-        }
         uint4 w;
-        w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
-        w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+        if (a.bf16) {
+            unsigned short v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = l == 0 ? 32 * ks + 8 * q + s : 16 * (2 * ks + (s >> 2)) + 4 * q + (s & 3);
+                v[s] = f2bf((j < J && k < K) ? a.W[l][(long)j * K + k] : 0.f);
+            }
+            w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
+            w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+        } else { // fp32: k = 16 ks + 4q + r in every layer (layer 0: the feature row; later: the previous accumulators)
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * ks + 4 * q + r;
+                v[r] = (j < J && k < K) ? a.W[l][(long)j * K + k] : 0.f;
+            }
+            w.x = __float_as_uint(v[0]); w.y = __float_as_uint(v[1]); w.z = __float_as_uint(v[2]); w.w = __float_as_uint(v[3]);
+        }
         *(uint4*)(dst + (size_t)F * 1024 + lane * 16) = w;
     }
     float* bias = (float*)(dst + a.stream_bytes);
@@ -1424,12 +1438,12 @@ std::string jit_source(const JitSpec& j) {
 // wide bf16 MLP: layer widths, activation and frames per wave as constants
 std::string jit_source_chain(const ChainGeom& g, int act, int fb) {
     std::string s = "// preamble generated from the plan\n";
-    char t[64];
+    char t[160];
     snprintf(t, sizeof(t), "constexpr int NL = %d;\n", g.nl); s += t;
     s += "constexpr int DIMS[] = {";
     for (int i = 0; i <= g.nl; ++i) { snprintf(t, sizeof(t), "%s%d", i ? ", " : "", g.dims[i]); s += t; }
     s += "};\n";
-    snprintf(t, sizeof(t), "constexpr int ACT = %d;\nconstexpr int FB = %d;\n", act, fb); s += t;
+    snprintf(t, sizeof(t), "constexpr int ACT = %d;\nconstexpr int FB = %d;\nconstexpr bool BF16 = %s;\n", act, fb, g.bf16 ? "true" : "false"); s += t;
     s += "#line 1 \"molann_mlp_jit.inc\"\n";
     s += join_chunks(k_src_molann_mlp_jit_inc);
     return s;
@@ -1653,7 +1667,8 @@ int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, 
             {feat, out, p->d_wchain, (const float*)(p->d_wchain + p->chain_stream_bytes), n_frames, in_stride};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-        snprintf(p->mlp_info, sizeof(p->mlp_info), "molann_mlp_chain<bf16,FB=%d> (plan-specialised) grid=%d block=256", p->chain_fb, grid);
+        snprintf(p->mlp_info, sizeof(p->mlp_info), "molann_mlp_chain<%s,FB=%d> (plan-specialised) grid=%d block=256",
+                 p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->chain_fb, grid);
         return (int)hipModuleLaunchKernel(p->chain_fn, grid, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg);
     }
     MlpArgs a;
@@ -1882,8 +1897,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     memset(&cg, 0, sizeof(cg));
     size_t chain_bytes = 0;
     int chain_fb = 0;
-    if (bf16 && d->n_layers > 0 && !p->fused_mlp) {
+    if (d->n_layers > 0 && !p->fused_mlp) {
         cg.nl = d->n_layers;
+        cg.bf16 = bf16 ? 1 : 0;
         for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = p->dims[i];
         for (int fb = 4; fb >= 1 && chain_fb == 0; --fb) // upper bound; plan creation steps down while the build spills
             if (fb * cg.regs_per_fb() <= 512) chain_fb = fb;
@@ -2105,10 +2121,11 @@ int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* c
         ChainGeom g;
         memset(&g, 0, sizeof(g));
         g.nl = p->n_layers;
+        g.bf16 = p->mlp_prec == MOLANN_MLP_BF16 ? 1 : 0;
         for (int i = 0; i <= p->n_layers; ++i) g.dims[i] = p->dims[i];
         ChainPackArgs c;
         memset(&c, 0, sizeof(c));
-        c.n_layers = g.nl; c.npair = g.npair(); c.stream_bytes = p->chain_stream_bytes;
+        c.n_layers = g.nl; c.npair = g.npair(); c.bf16 = g.bf16; c.stream_bytes = p->chain_stream_bytes;
         for (int i = 0; i <= g.nl; ++i) { c.dims[i] = g.dims[i]; c.bias_off[i] = g.bias_off(i); }
         for (int l = 0; l < g.nl; ++l) { c.W[l] = W[l]; c.b[l] = b[l]; }
         int start = 0;
@@ -2282,6 +2299,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
         ChainGeom cg;
         memset(&cg, 0, sizeof(cg));
         cg.nl = d->n_layers;
+        cg.bf16 = d->mlp_precision == MOLANN_MLP_BF16 ? 1 : 0;
         for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = d->layer_dims[i];
         int fb = 0;
         for (int f = 4; f >= 1 && fb == 0; --f)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ACTS = {_capi.ACT_TANH: torch.tanh, _capi.ACT_RELU: torch.relu, _capi.ACT_SIGMOID: torch.sigmoid}
 
 
-def _plan(dims, act, n_inp=128):
+def _plan(dims, act, n_inp=128, precision=_capi.MLP_BF16):
     """A plan whose feature dimension is dims[0]: positions of dims[0]//3 atoms (+ a bond / a dihedral)."""
     k, r = divmod(dims[0], 3)
     feats = [(_capi.FEAT_POSITION, list(range(k)))] if k else []
@@ -20,7 +20,7 @@ def _plan(dims, act, n_inp=128):
         feats.append((_capi.FEAT_BOND, [k, k + 1]))
     elif r == 2:
         feats.append((_capi.FEAT_DIHEDRAL, [k, k + 1, k + 2, k + 3]))
-    return _capi.Plan(n_inp, features=feats, layer_dims=dims, activation=act, mlp_precision=_capi.MLP_BF16)
+    return _capi.Plan(n_inp, features=feats, layer_dims=dims, activation=act, mlp_precision=precision)
 
 
 def _bf16(t):
@@ -98,3 +98,31 @@ def test_chain_kernel_rereads_updated_weights(hip_device):
         torch.cuda.synchronize()
         want = _emulate(f, ws, bs, act)
         assert float((out.cpu() - want).abs().max()) <= 4e-3 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dims,act", [
+    ([85, 128, 64, 8], _capi.ACT_TANH),          # C4
+    ([6, 64, 64, 8], _capi.ACT_TANH),            # a wide MLP behind C3's six features
+    ([341, 512, 256, 16], _capi.ACT_TANH),
+    ([40, 33, 7], _capi.ACT_SIGMOID),
+    ([70, 5], _capi.ACT_TANH),
+    ([50, 64, 32, 48, 5], _capi.ACT_RELU),
+    ([33, 40, 24, 36, 20, 9], _capi.ACT_TANH),
+])
+@pytest.mark.parametrize("n", [1, 255, 1000])
+def test_fp32_chain_kernel_is_fp32(dims, act, n, hip_device):
+    """The same kernel on the fp32 MFMA (exact fp32 products, fp32 accumulation): within 1e-5 of a float64 MLP."""
+    plan = _plan(dims, act, precision=_capi.MLP_F32)
+    ws, bs = _params(dims, hip_device, 11)
+    plan.update_mlp(ws, bs)
+    f = torch.randn(n, dims[0], device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(n))
+    out = torch.full((n, dims[-1]), float("nan"), device=hip_device)
+    plan.mlp_packed(f, out)
+    torch.cuda.synchronize()
+    assert "molann_mlp_chain<f32" in plan.last_launch_info(), plan.last_launch_info()
+    h = f.cpu().double()
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        h = h @ w.cpu().double().T + b.cpu().double()
+        if i + 1 < len(ws):
+            h = ACTS[act](h)
+    assert float((out.cpu().double() - h).abs().max()) <= 1e-5 * max(1.0, float(h.abs().max()))
