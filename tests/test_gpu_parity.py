@@ -313,3 +313,24 @@ def test_host_trajectory_streamer(hip_device):
     # a pinned torch tensor crosses the link from where it lies (no staging copy); a pageable one is staged
     assert np.array_equal(stream_forward(model, x.clone().pin_memory(), chunk_frames=3000, device=hip_device), want)
     assert np.array_equal(stream_forward(model, x, chunk_frames=3000, device=hip_device), want)
+
+
+def test_hip_graph_replay_of_the_two_stream_path(hip_device):
+    """An MLP outside the fused lane kernel: feature kernel on the caller's stream, chain MLP kernel on the plan's
+    side stream, fork/join by events - all of it capturable into one HIP graph."""
+    from molann_amd.graph import GraphedForward
+    from molann_amd.ann import MolANN, create_sequential_nn, last_launch_info
+    w = wl.get_workload("C3")
+    base = workload_model(w, hip_device)
+    torch.manual_seed(3)
+    model = MolANN(base.preprocessing_layer, create_sequential_nn([6, 64, 64, 8]).to(hip_device)).requires_grad_(False)
+    x = w.make_frames(300000, seed=41).to(hip_device)        # more than one workspace chunk
+    want = _run(model, x)
+    assert "molann_mlp_chain<f32" in last_launch_info(model), last_launch_info(model)
+    g = GraphedForward(model, x)
+    for seed in (42, 43):
+        x2 = w.make_frames(300000, seed=seed).to(hip_device)
+        got = g(x2).cpu()
+        assert torch.equal(got, _run(model, x2))
+    ref = oracle_for_workload(w, model, x[:2000].cpu(), torch.float64)
+    assert float((want[:2000].double() - ref).abs().max()) <= F32_TOL
