@@ -1422,6 +1422,11 @@ void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fa
     } else {
         lane_geometry(g, tile, fallback_cols);
         j.nbuf = 1;
+        // the kernel runs 2 (or 3) waves per SIMD = 8 (12) per CU: a block size that divides them
+        if (g.ok && g.wpb == 3) {
+            const long L = g.lds_per_wave;
+            g.wpb = (4 * L <= 65536 && 8 * L <= 163840) ? 4 : 2;
+        }
     }
     j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
 }
@@ -1916,7 +1921,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         // feature chunk handed from the preprocessing kernel to the MLP kernel: sized to stay
         // resident in the 256 MiB Infinity Cache
         long wf = (64l << 20) / ((long)d_feat * 4);
-        wf = std::max<long>(1024, std::min<long>(wf, 1l << 18));
+        wf = std::max<long>(1024, std::min<long>(wf, 1l << 20)); // (narrow feature rows: few, large chunks - each costs ~6 host API calls)
         wf &= ~63l;
         wf = std::max<long>(512, (wf / 2) & ~63l); // per half
         p->work_frames = wf;
