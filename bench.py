@@ -9,10 +9,17 @@ backbone atoms + 4 features + MLP [6,32,8]) over 1,048,576 frames per GPU; C1/C2
 other configs) are selectable.  Inputs rotate over several distinct buffers (> 1 GiB in total for the
 22-atom configs) so that timed reads come from HBM, not from the 256 MiB Infinity Cache.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): frames are sharded, every rank
-runs the same K steps on its own shard (weak scaling, no data-path collective) and ONE all-gather of the
-last step's output shards closes the timed region (BASELINE.json: "RCCL all-gather of outputs ... only
-at the end").  The time is the max over ranks; value = all frames of all ranks / that time.
+N > 1: one process per GPU over RCCL.  Either the driver starts the ranks (torch.distributed.run sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or `python bench.py --gpus N` run plainly starts them itself:
+the parent counts the devices WITHOUT initialising the GPU, spawns N children with that environment and
+exits with their status (it never touches the GPU, and a rank that fails takes the run down, non-zero).
+Frames are sharded, every rank runs the same K steps on its own shard (weak scaling, no data-path
+collective) and ONE all-gather of the last step's output shards closes the timed region (BASELINE.json:
+"RCCL all-gather of outputs ... only at the end").  That gather either follows the last step as one
+`all_gather_into_tensor` ("collective"), or runs beside it ("overlap": the last step goes in chunks and chunk i
+travels - each peer's rows straight into their final place over that peer's own xGMI link - while chunk i+1
+computes); the warm-up times both on the live communicator and the timed region uses the faster one.
+The time is the max over ranks; value = all frames of all ranks / that time.
 
 One JSON line on rank 0; besides the contract's keys it carries
   roofline      the dominant kernel against the 8 TB/s HBM roof: algorithmic bytes per launch (SURVEY.md
@@ -20,11 +27,17 @@ One JSON line on rank 0; besides the contract's keys it carries
                 with HIP events on the launch stream around the timed steps
   cpu_baseline  the oracle (composite-PyTorch restatement of the reference's op sequence) timed on this
                 box's host cores on a bounded sample (N = 1 only)
+  config.env    every MOLANN_* variable present; a variable that changes what is computed
+                (MOLANN_ELIDE_INVARIANT_ALIGNMENT, MOLANN_DEBUG_*) makes the bench refuse to report a
+                value unless --diagnostic is given, and the line then says "diagnostic": true
+  config.dist   world size, backend and the device of every rank, as torch.distributed reports them
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,12 +48,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from molann_amd import workloads as wl  # noqa: E402
+from molann_amd import dist as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # measured float4 copy (same guide)
 
+# variables that change WHAT is computed (or skip part of it): a line measured under one is not a result
+RESULT_CHANGING_ENV = ("MOLANN_ELIDE_INVARIANT_ALIGNMENT", "MOLANN_DEBUG_")
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -51,7 +68,159 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the final all-gather out")
-    return ap.parse_args()
+    ap.add_argument("--gather-mode", default="auto", choices=("auto", "collective", "overlap"),
+                    help="N>1: how the one all-gather is issued (auto: both timed in the warm-up, faster one kept)")
+    ap.add_argument("--gather-chunks", type=int, default=4, help="overlap mode: pieces the last step is cut into")
+    ap.add_argument("--diagnostic", action="store_true",
+                    help="allow result-changing MOLANN_* switches; the line is then marked diagnostic")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------
+# environment certification
+# ------------------------------------------------------------------------------------------------------
+
+def molann_env(environ=None):
+    environ = os.environ if environ is None else environ
+    return {k: environ[k] for k in sorted(environ) if k.startswith("MOLANN_")}
+
+
+def result_changing(env):
+    """The MOLANN_* switches in `env` that alter or skip part of the computation (set to anything but ''/'0')."""
+    bad = []
+    for k, v in env.items():
+        if any(k == p or (p.endswith("_") and k.startswith(p)) for p in RESULT_CHANGING_ENV) and v not in ("", "0"):
+            bad.append(k)
+    return bad
+
+
+def check_env(args, environ=None):
+    env = molann_env(environ)
+    bad = result_changing(env)
+    if bad and not args.diagnostic:
+        raise SystemExit("bench.py: %s set - that changes what the kernels compute; no value is reported "
+                         "(pass --diagnostic for a line marked as such)" % ", ".join(bad))
+    return env, bool(bad)
+
+
+def gpu_clocks(index):
+    """Current / maximum shader and memory clocks from sysfs where readable (None otherwise)."""
+    out = {}
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if index < len(cards):
+            base = os.path.dirname(cards[index])
+            for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+                lines = open(os.path.join(base, fn)).read().split("\n")
+                levels = [ln.split(":", 1)[1].strip() for ln in lines if ":" in ln]
+                cur = [ln.split(":", 1)[1].replace("*", "").strip() for ln in lines if ln.strip().endswith("*")]
+                out[key] = {"current": cur[0] if cur else None, "levels": levels}
+    except Exception:
+        pass
+    return out or None
+
+
+# ------------------------------------------------------------------------------------------------------
+# the parent of a plain `bench.py --gpus N`: starts the ranks, never touches the GPU
+# ------------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, device_count=None, popen=subprocess.Popen):
+    """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment) and
+    return the exit status of the run: 0 only if every rank returned 0.  The caller has made no GPU call."""
+    have = torch.cuda.device_count() if device_count is None else device_count   # does not initialise the GPU
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); not running a smaller job under "
+                         "that name\n" % (n, have))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    status, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                sys.stderr.write("bench.py: rank process %d exited with %d; stopping the others\n" % (p.pid, rc))
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    return status
+
+
+# ------------------------------------------------------------------------------------------------------
+# what a rank runs on: the MI355X (the only thing the command line ever builds)
+# ------------------------------------------------------------------------------------------------------
+
+class HipSide(object):
+    """Device, model, frames, timers and synchronisation of one rank on its MI355X."""
+    backend = "nccl"
+
+    def __init__(self, local_rank):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU path)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: local rank %d but %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.index = local_rank
+
+    def init_process_group(self):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:      # the one-rank rehearsal (MOLANN_BENCH_FORCE_DIST=1) run plainly
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(self.index))
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(backend=self.backend, device_id=self.device)
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier(device_ids=[self.index])
+
+    def describe(self):
+        p = torch.cuda.get_device_properties(self.device)
+        return "cuda:%d %s (%s)" % (self.index, p.name, getattr(p, "gcnArchName", "?"))
+
+    def build_model(self, w):
+        model = wl.build_model(w, self.device)
+        model.requires_grad_(False)
+        return model
+
+    def make_frames(self, w, n, seed):
+        return w.make_frames(n, device=self.device, seed=seed)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def mark(self):
+        e = torch.cuda.Event(enable_timing=True)   # on the current stream = the stream the kernels are launched on
+        e.record()
+        return e
+
+    def wait_mark(self, e):
+        e.synchronize()
+
+    def ms_between(self, a, b):
+        return a.elapsed_time(b)
+
+    def kernels(self, model):
+        from molann_amd.ann import last_launch_info
+        return last_launch_info(model)
 
 
 def host_cores():
@@ -79,7 +248,8 @@ def host_cores():
 
 
 def cpu_baseline(w, model, seconds):
-    """The oracle on the host cores, full batch in 64k-frame chunks."""
+    """The oracle on the host cores over the workload's own batch: the 1M-frame configs in 64k-frame chunks
+    (a 262 144-frame sample), C1 at its batch of 1024, 5000-atom frames 2048 at a time."""
     from oracle import molann_oracle as mo
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -92,8 +262,8 @@ def cpu_baseline(w, model, seconds):
         ws = [l.weight.detach().float().cpu() for l in lins]
         bs = [l.bias.detach().float().cpu() for l in lins]
     small = w.n_atoms <= 64
-    n = (1 << 18) if small else 2048
-    chunk = (1 << 16) if small else 512
+    n = min(w.frames, 1 << 18) if small else 2048
+    chunk = min(n, 1 << 16) if small else 512
     x = w.make_frames(n, seed=4321)
 
     def one_pass():
@@ -112,7 +282,8 @@ def cpu_baseline(w, model, seconds):
     t_start = time.perf_counter()
     one_pass()  # warm-up
     times = []
-    while len(times) < 7 and (not times or (time.perf_counter() - t_start) < seconds):
+    most = 7 if n >= (1 << 16) else 2001
+    while len(times) < most and (not times or (time.perf_counter() - t_start) < seconds):
         times.append(one_pass())
     times.sort()
     med = times[len(times) // 2]
@@ -121,82 +292,116 @@ def cpu_baseline(w, model, seconds):
                       % (len(times), n, chunk, torch.__version__, cores)}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("MOLANN_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL calls on one rank
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+# ------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------
 
+def pick_buffers(args, buf_bytes):
+    nbuf = args.buffers if args.buffers > 0 else max(2, min(8, -(-(5 << 28) // max(1, buf_bytes))))  # > 1.25 GiB in total
+    if buf_bytes > (8 << 30) and args.buffers <= 0:
+        nbuf = 2
+    return nbuf
+
+
+def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, emit=print):
+    """K timed steps of the workload on this rank's shard (+ the one all-gather when distributed) and, on rank 0, the
+    JSON line.  `side` supplies device, model, frames, timers (HipSide on the command line; tests hand in a CPU
+    stand-in to drive this very code over gloo)."""
+    import torch.distributed as dist
     w = wl.get_workload(args.workload)
     frames = args.frames if args.frames > 0 else w.frames
-    model = wl.build_model(w, dev)
-    model.requires_grad_(False)
+    model = side.build_model(w)
+    gather = distributed and not args.no_gather
 
     # ---- inputs resident in HBM before the clock starts ---------------------------------------
-    buf_bytes = frames * w.n_atoms * 12
-    nbuf = args.buffers if args.buffers > 0 else max(2, min(8, -(-(5 << 28) // buf_bytes)))  # > 1.25 GiB in total
-    if buf_bytes > (8 << 30):
-        nbuf = 2 if args.buffers <= 0 else nbuf
-    xs = [w.make_frames(frames, device=dev, seed=w.seed + 1000 * rank + i) for i in range(nbuf)]
-    torch.cuda.synchronize()
+    nbuf = pick_buffers(args, frames * w.n_atoms * 12)
+    xs = [side.make_frames(w, frames, w.seed + 1000 * rank + i) for i in range(nbuf)]
+    side.sync()
+    barrier = side.barrier if distributed else (lambda: None)
 
-    def barrier():
-        if distributed:
-            dist.barrier(device_ids=[local_rank])
+    gat = None
+    if gather:
+        gat = mdist.OutputGather(frames, w.out_dim(), xs[0].device, world, rank, chunks=max(1, args.gather_chunks))
+
+    def last_step(x, mode):
+        """The K-th step and the all-gather of its outputs; returns the gathered [N, d_out]."""
+        if mode == "overlap":
+            return gat.forward_overlapped(model, x)
+        return gat.collective(model(x))
 
     with torch.no_grad():
         for i in range(args.warmup):
             y = model(xs[i % nbuf])
-        if distributed and not args.no_gather:
-            from molann_amd.dist import all_gather_outputs
-            all_gather_outputs(y, frames * world)   # equal shards: no size exchange, one collective
-        torch.cuda.synchronize()
+        tune = None
+        mode = args.gather_mode
+        if gather:
+            # both forms once untimed (communicator set-up, first-use allocations), then timed on the live communicator
+            tune = {}
+            for m in (("collective", "overlap") if mode == "auto" else (mode,)):
+                last_step(xs[0], m)
+                side.sync()
+                barrier()
+                ts = []
+                for rep in range(3):
+                    side.sync()
+                    t0 = time.perf_counter()
+                    last_step(xs[rep % nbuf], m)
+                    side.sync()
+                    ts.append(time.perf_counter() - t0)
+                tune[m] = sorted(ts)[1] * 1e3
+            if mode == "auto":
+                t = torch.tensor([tune["collective"], tune["overlap"]], dtype=torch.float64, device=xs[0].device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)          # every rank takes the same decision
+                tune = {"collective": float(t[0]), "overlap": float(t[1])}
+                mode = "overlap" if tune["overlap"] < tune["collective"] else "collective"
+        side.sync()
 
-        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        # ---- the timed region: barrier + synchronize on both sides, EXACTLY K steps (+ the one all-gather) ------
         barrier()
-        torch.cuda.synchronize()
+        side.sync()
         t0 = time.perf_counter()
-        ev0.record()
-        for i in range(args.steps):
+        ev0 = side.mark()
+        n_plain = args.steps - 1 if gather else args.steps
+        for i in range(n_plain):
             y = model(xs[i % nbuf])
-        ev1.record()
-        if distributed and not args.no_gather:
-            y_all = all_gather_outputs(y, frames * world)
-        ev2.record()
-        torch.cuda.synchronize()
+        ev1 = side.mark()
+        if gather:
+            y_all = last_step(xs[n_plain % nbuf], mode)
+        ev2 = side.mark()
+        side.sync()
+        elapsed = time.perf_counter() - t0      # this rank's K steps; the job's time is the max over ranks (below)
         barrier()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration, launch stream
-        gather_ms = ev1.elapsed_time(ev2)                # the one all-gather (0 when there is none)
+        kernel_ms = side.ms_between(ev0, ev1) / n_plain if n_plain > 0 else None
+        tail_ms = side.ms_between(ev1, ev2) if gather else 0.0   # last step + all-gather, however they were interleaved
+        if gather:
+            assert tuple(y_all.shape) == (frames * world, w.out_dim())
 
-        # per-launch durations (outside the timed region) for the spread
+        # individually synchronised launches (outside the timed region): each includes the host's launch latency
         per = []
         for i in range(min(args.steps, 20)):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            a = side.mark()
             model(xs[i % nbuf])
-            b.record()
-            b.synchronize()
-            per.append(a.elapsed_time(b))
+            b = side.mark()
+            side.wait_mark(b)
+            per.append(side.ms_between(a, b))
         per.sort()
+        # shader / memory clock while the kernel runs (sysfs, where readable): read with launches in flight
+        for i in range(60):
+            model(xs[i % nbuf])
+        clocks = gpu_clocks(getattr(side, "index", 0))
+        side.sync()
+        if kernel_ms is None:       # --steps 1 with the gather: no plain step inside the timed region
+            kernel_ms = per[len(per) // 2]
 
+    devices = [side.describe()]
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, kernel_ms, tail_ms], dtype=torch.float64, device=xs[0].device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        kmax = torch.tensor([kernel_ms, gather_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        kernel_ms, gather_ms = float(kmax[0].item()), float(kmax[1].item())
+        elapsed, kernel_ms, tail_ms = (float(v) for v in tmax)
+        devices = [None] * world
+        dist.all_gather_object(devices, side.describe())
 
+    rec = None
     if rank == 0:
         total_frames = frames * world * args.steps
         value = total_frames / elapsed
@@ -207,11 +412,11 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(w.name, {}).get("bytes_per_launch")
+                t = json.load(open(tfile)).get(w.name, {})
+                if t.get("frames_per_launch") in (None, frames):
+                    traffic = t.get("bytes_per_launch")
             except Exception:
                 traffic = None
-        from molann_amd.ann import last_launch_info
-        plan_info = last_launch_info(model)
         rec = {
             "metric": "frames/sec (MolANN forward, 22-atom ala-dipeptide)" if w.n_atoms == 22 else
                       "frames/sec (MolANN forward, %d-atom system)" % w.n_atoms,
@@ -219,31 +424,68 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if w.mlp_dtype != "bf16" else "f32 (Kabsch 3x3 in f64) + bf16 MLP",
             "data": "synthetic",
-            "config": {"workload": "%s: %s" % (w.name, w.description), "frames_per_gpu": frames,
+            "config": {"workload": "%s: %s, %d frames/GPU" % (w.name, w.description, frames), "frames_per_gpu": frames,
                        "n_atoms": w.n_atoms, "align_atoms": len(w.align) if w.align else 0,
                        "features": len(w.features), "feature_dim": w.feature_dim(),
                        "mlp": w.mlp_dims, "input_buffers": nbuf, "parallelism": "frames sharded x%d" % world,
-                       "final_allgather": bool(distributed and not args.no_gather), "kernels": plan_info},
+                       "final_allgather": bool(gather), "kernels": side.kernels(model),
+                       "env": env if env is not None else molann_env(),
+                       "dist": {"world_size": dist.get_world_size() if distributed else 1,
+                                "backend": dist.get_backend() if distributed else None,
+                                "devices": devices, "launched_by": os.environ.get("MOLANN_BENCH_LAUNCHER", "self" if not distributed else "external")},
+                       "clocks_under_load": clocks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_frame": alg_bytes, "dense_bytes_per_frame": dense_bytes,
                          "dense_GBps": dense_bytes * frames / (kernel_ms * 1e-3) / 1e9,
                          "dense_frac_of_measured_copy_bw": dense_bytes * frames / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
-                         "launch_ms_avg": kernel_ms, "launch_ms_min": per[0], "launch_ms_median": per[len(per) // 2]},
+                         "launch_ms_avg": kernel_ms,
+                         "synced_launch_ms_min": per[0], "synced_launch_ms_median": per[len(per) // 2]},
         }
+        if diagnostic:
+            rec["diagnostic"] = True
         if distributed:
-            # value (above) is the contract's number: K steps + the final all-gather + both barriers, max over ranks.
-            # The same run split into its two phases (HIP events, max over ranks), because one all-gather of
+            # value (above) is the contract's number: K steps with the all-gather of the K-th step's outputs, max over
+            # ranks.  The same run split into its phases (HIP events, max over ranks), because one all-gather of
             # 7 x [frames, d_out] per rank over xGMI costs as much as several 22-atom steps:
             rec["phases"] = {"compute_ms_per_step": kernel_ms, "compute_frames_per_s": frames * world / (kernel_ms * 1e-3),
-                             "allgather_ms": gather_ms,
-                             "allgather_bytes_received_per_rank": (world - 1) * frames * int(y.shape[1]) * 4}
+                             "last_step_plus_allgather_ms": tail_ms,
+                             "allgather_exposed_ms": max(0.0, tail_ms - kernel_ms) if gather else 0.0,
+                             "allgather_mode": mode if gather else None,
+                             "allgather_chunks": gat.chunks if (gather and mode == "overlap") else (1 if gather else 0),
+                             "allgather_warmup_ms": tune,
+                             "allgather_bytes_received_per_rank": (world - 1) * frames * w.out_dim() * 4 if gather else 0}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w, model, args.cpu_seconds)
             rec["gpu_over_cpu"] = value / rec["cpu_baseline"]["value"]
-        print(json.dumps(rec))
+        emit(json.dumps(rec))
+    return rec
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env, diagnostic = check_env(args)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # plain `bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU.
+        os.environ["MOLANN_BENCH_LAUNCHER"] = "bench.py"
+        sys.exit(launch_ranks(args.gpus, argv))
+    world = int(world_env or "1")
+    if world_env is not None and args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or os.environ.get("MOLANN_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL calls on one rank
+    side = HipSide(local_rank)
     if distributed:
-        dist.destroy_process_group()
+        side.init_process_group()
+    try:
+        run_rank(args, side, world, rank, distributed, env=env, diagnostic=diagnostic)
+    finally:
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -15,9 +15,11 @@
  *     by the caller; pointers inside molann_plan_desc are HOST pointers, read during plan_create only.
  *   - launch functions only enqueue work on `stream`: no host synchronisation, no allocation
  *     (graph-capturable).  They are thread-safe for distinct plans; one plan may be used from several
- *     streams as long as molann_plan_update_* calls are ordered before the launches that need them -
- *     except a plan whose MLP is not fused into the frame kernel (wide MLPs / large frames): it owns a
- *     feature workspace, a side stream and events, so its forward calls must not overlap each other.
+ *     streams as long as molann_plan_update_* calls are ordered before the launches that need them.
+ *     A plan whose MLP is not fused into the frame kernel (wide MLPs / large frames) owns a feature
+ *     workspace, a side stream and events: its forward calls are serialised by the library itself (a
+ *     host mutex around the enqueue; a caller on another stream first waits for the event recorded
+ *     behind the previous call), so they are safe from any stream or thread but do not overlap.
  *   - x is [n_frames, n_inp, 3] fp32, contiguous, frame-major / atom-major / xyz-minor (the layout of
  *     the tensor the reference's forward receives, ann.py:170).  Any 4-byte aligned pointer works;
  *     16-byte aligned pointers take the wide-load path.
@@ -171,6 +173,10 @@ int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out
 
 /* -- misc ------------------------------------------------------------------------------------- */
 int molann_abi_version(void);
+/* "release" (the product library: reads no switch that changes or skips part of the computation) or
+ * "diagnostics" (libmolann_hip_diag.so, `make diag`: additionally honours MOLANN_DEBUG_*,
+ * MOLANN_ELIDE_INVARIANT_ALIGNMENT, MOLANN_JIT_EXTRA_FLAGS for tools/; never used for a reported number). */
+const char* molann_build_kind(void);
 const char* molann_error_string(int code);
 /* Name + launch geometry of the kernels the last launch on this plan used (for bench / profiles).
  * Writes a NUL-terminated string of at most `cap` bytes; returns its length. */

@@ -15,6 +15,8 @@ import torch  # imported first so that libamdhip64.so.7 is torch's copy (same SO
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmolann_hip.so")
+# the diagnostics build (honours MOLANN_DEBUG_* / MOLANN_ELIDE_INVARIANT_ALIGNMENT): tools/ only, opt-in by name
+DIAG_LIB_PATH = os.path.join(_CSRC, "libmolann_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "molann_hip.h")
 
 ABI_VERSION = 1
@@ -61,13 +63,16 @@ def lib():
     """The loaded library (raises if it has not been built: no silent fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("%s not found: run `make -C %s` (or __graft_entry__.build())" % (LIB_PATH, _CSRC))
-        L = ctypes.CDLL(LIB_PATH)
+        path = DIAG_LIB_PATH if os.environ.get("MOLANN_DIAG_LIB") == "1" else LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError("%s not found: run `make -C %s%s` (or __graft_entry__.build())"
+                              % (path, _CSRC, " diag" if path == DIAG_LIB_PATH else ""))
+        L = ctypes.CDLL(path)
         vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         sigs = {
             "molann_abi_version": (i32, []),
             "molann_error_string": (ctypes.c_char_p, [i32]),
+            "molann_build_kind": (ctypes.c_char_p, []),
             "molann_plan_create": (i32, [ctypes.POINTER(PlanDesc), ctypes.POINTER(vp)]),
             "molann_plan_destroy": (i32, [vp]),
             "molann_plan_feature_dim": (i32, [vp]),
@@ -108,6 +113,11 @@ def declared_symbols():
     text = open(HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(molann_[a-z0-9_]+)\s*\(", text)))
+
+
+def build_kind():
+    """"release" or "diagnostics" (see include/molann_hip.h)."""
+    return lib().molann_build_kind().decode()
 
 
 def error_string(code):

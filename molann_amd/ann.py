@@ -131,6 +131,14 @@ def _device_input(x, grad_sources=(), backward_ok=False):
     return x if x.is_contiguous() else x.contiguous()
 
 
+def _release_plans(desc, device):
+    """weakref.finalize callback of a MolANN: its plans in the operator library's cache go with it."""
+    try:
+        torch.ops.molann.release(desc, device)
+    except Exception:   # interpreter shutdown / library gone
+        pass
+
+
 class _PlanFunction(torch.autograd.Function):
     """forward = one fused launch of the plan; backward = molann_backward_f32 (recomputes the forward per
     frame, nothing but x is saved).  `params` are the Linear weights/biases in layer order (may be empty)."""
@@ -148,6 +156,7 @@ class _PlanFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # the backward is a kernel: first-order only, and it says so
     def backward(ctx, grad_out):
         (x,) = ctx.saved_tensors
         plan = ctx.entry.plan
@@ -189,6 +198,20 @@ class _PlanOwner(object):
             self.__dict__["_plan_cache"] = cache
         return cache
 
+    def refresh_parameters(self):
+        """Re-read `ref_x` and the Linear parameters at the next forward.  Needed only after writing them in a way
+        their version counters do not show (`p.data.mul_()`, `p.data.copy_()`, a detached alias): ordinary in-place
+        ops, optimizer steps, load_state_dict, .to() and replaced Parameters are seen without it."""
+        for e in self._plans().values():
+            if isinstance(e, _PlanEntry):
+                e.invalidate()
+        st = self.__dict__.get("_fast")
+        if st is not None and st.get("desc") is not None and st.get("op") is not None:
+            torch.ops.molann.invalidate(st["desc"], st["sig"][5])
+        for m in self.children():
+            if isinstance(m, _PlanOwner):
+                m.refresh_parameters()
+
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_plan_cache", None)
@@ -206,8 +229,17 @@ class _PlanOwner(object):
         return new
 
 
-def _tensor_key(t):
-    return (t.data_ptr(), t._version, t.device.index)
+class _TensorKey(object):
+    """Which tensor was packed: the OBJECT (weak reference: an address the allocator reuses cannot pass for it), its
+    storage address and its version counter.  In-place writes through `.data` bump neither: `refresh_parameters()`."""
+    __slots__ = ("ref", "ptr", "version")
+
+    def __init__(self, t):
+        import weakref
+        self.ref, self.ptr, self.version = weakref.ref(t), t.data_ptr(), t._version
+
+    def matches(self, t):
+        return self.ref() is t and self.ptr == t.data_ptr() and self.version == t._version
 
 
 class _PlanEntry(object):
@@ -218,21 +250,24 @@ class _PlanEntry(object):
         self.ref_key = None
         self.mlp_key = None
 
+    def invalidate(self):
+        self.ref_key = self.mlp_key = None
+
     def sync_ref(self, ref_x):
-        key = _tensor_key(ref_x)
-        if key != self.ref_key:
+        if self.ref_key is None or not self.ref_key.matches(ref_x):
             r = ref_x if (ref_x.dtype == torch.float32 and ref_x.is_contiguous()) else ref_x.float().contiguous()
             self.plan.update_ref(r)
-            self.ref_key = key
+            self.ref_key = _TensorKey(ref_x)
             self._ref_hold = r
 
     def sync_mlp(self, linears):
-        key = tuple(_tensor_key(p) for lin in linears for p in (lin.weight, lin.bias))
-        if key != self.mlp_key:
+        params = [p for lin in linears for p in (lin.weight, lin.bias)]
+        if self.mlp_key is None or len(self.mlp_key) != len(params) or \
+                not all(k.matches(p) for k, p in zip(self.mlp_key, params)):
             ws = [lin.weight.detach().contiguous() for lin in linears]
             bs = [lin.bias.detach().contiguous() for lin in linears]
             self.plan.update_mlp(ws, bs)
-            self.mlp_key = key
+            self.mlp_key = [_TensorKey(p) for p in params]
 
 
 def _feature_spec(feature_layer_or_map):
@@ -537,6 +572,8 @@ class MolANN(_PlanOwner, torch.nn.Module):
                                               features=spec, use_angle_value=uav, layer_dims=dims, activation=act,
                                               mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
                 st["no_ref"] = torch.zeros(0, 3)
+                import weakref
+                weakref.finalize(self, _release_plans, st["desc"], x.device.index)
         self.__dict__["_fast"] = st
         return st
 

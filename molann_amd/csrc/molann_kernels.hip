@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <new>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1159,13 +1160,26 @@ __global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ ds
 
 inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
-// diagnostic switches, read once per process (never on the launch path)
+// Switches that change WHAT is computed, skip part of it, or exist only for experiments (MOLANN_DEBUG_*,
+// MOLANN_ELIDE_INVARIANT_ALIGNMENT, MOLANN_JIT_EXTRA_FLAGS) are read by the diagnostics build alone
+// (`make diag` -> libmolann_hip_diag.so, -DMOLANN_DIAGNOSTICS; tools/ loads it with MOLANN_DIAG_LIB=1).  The
+// product library never looks at them: molann_build_kind() says which one is loaded.
+inline const char* diag_env(const char* name) {
+#ifdef MOLANN_DIAGNOSTICS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// switches read once per process (never on the launch path)
 struct DebugEnv {
     int ablate, lds_pad, wave_bpc, wave_pre;
     DebugEnv() {
         const char* e;
-        ablate = (e = getenv("MOLANN_DEBUG_ABLATE")) ? atoi(e) : 0;
-        lds_pad = (e = getenv("MOLANN_DEBUG_LDS_PAD")) ? atoi(e) : 0;
+        ablate = (e = diag_env("MOLANN_DEBUG_ABLATE")) ? atoi(e) : 0;
+        lds_pad = (e = diag_env("MOLANN_DEBUG_LDS_PAD")) ? atoi(e) : 0;
         wave_bpc = (e = getenv("MOLANN_WAVE_BPC")) ? atoi(e) : 0;
         wave_pre = (e = getenv("MOLANN_WAVE_PRE")) ? atoi(e) : -1; // item rounds preloaded by frames_wave_kernel
     }
@@ -1201,6 +1215,13 @@ struct molann_plan {
     long work_frames;
     hipStream_t side;  // the MLP kernel of chunk i runs here while the caller's stream gathers chunk i+1
     hipEvent_t ev_feat[2], ev_mlp[2];
+    // The workspace, the side stream and these events belong to the plan: forwards of one plan issued from different
+    // streams (or threads) are ordered one after the other - the host side by launch_mu, the device side by making a
+    // new caller's stream wait for ev_done, recorded behind the previous call's join.
+    hipEvent_t ev_done;
+    hipStream_t last_stream;
+    bool have_done;
+    std::mutex* launch_mu;
     int kp[MOLANN_MAX_LAYERS], jp[MOLANN_MAX_LAYERS];
     long moff[MOLANN_MAX_LAYERS];
     int mlp_ld[2], mlp_lds_per_wave;
@@ -1415,7 +1436,7 @@ void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fa
     const int tile = 64 * 16 * (int)j.win.size();
     const int fb = ceil_to(std::max(1, staging_rows) * FB_STRIDE * 4, 16);
     const long L2 = 2l * tile + fb;
-    const char* nb = getenv("MOLANN_DEBUG_JIT_NBUF"); // experiments: 2 = double-buffered tiles where they fit
+    const char* nb = diag_env("MOLANN_DEBUG_JIT_NBUF"); // experiments: 2 = double-buffered tiles where they fit
     if (nb && atoi(nb) == 2 && 2 * L2 <= 65536 && 8 * L2 <= 163840) { // blocks of 2 waves, 4 blocks per CU
         g.wpb = 2; g.lds_per_wave = (int)L2; g.fbuf_off = 2 * tile; g.ok = 1;
         j.nbuf = 2;
@@ -1491,11 +1512,11 @@ std::string jit_preamble(const JitSpec& j) {
     {   // Opt-in, never used for a reported number: a plan whose items are all invariant under rigid motion produces the
         // same output with or without its alignment; MOLANN_ELIDE_INVARIANT_ALIGNMENT=1 (read at plan creation) drops
         // the (then dead) Kabsch from the specialised kernel.  Default: the alignment is computed, as the reference does.
-        const char* e = getenv("MOLANN_ELIDE_INVARIANT_ALIGNMENT");
+        const char* e = diag_env("MOLANN_ELIDE_INVARIANT_ALIGNMENT");
         s += (e && e[0] == '1') ? "constexpr bool ELIDE_ALIGN = true;\n" : "constexpr bool ELIDE_ALIGN = false;\n";
     }
     {   // cache policy of the x stream's LDS-DMA (gfx940+ CPol bits: 1 = sc0, 2 = nt, 16 = sc1); experiments only
-        const char* e = getenv("MOLANN_DEBUG_DMA_AUX");
+        const char* e = diag_env("MOLANN_DEBUG_DMA_AUX");
         K("DMA_AUX", e ? atoi(e) : 0);
     }
     {
@@ -1552,7 +1573,7 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
     hiprtcResult r = rtc->create(&prog, src.c_str(), "molann_lane_jit.hip", 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return (int)r; }
     std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    if (const char* extra = getenv("MOLANN_JIT_EXTRA_FLAGS")) { // experiments: space-separated compiler flags
+    if (const char* extra = diag_env("MOLANN_JIT_EXTRA_FLAGS")) { // experiments: space-separated compiler flags
         std::string e(extra);
         size_t pos = 0;
         while (pos < e.size()) {
@@ -1719,6 +1740,14 @@ extern "C" {
 
 int molann_abi_version(void) { return MOLANN_ABI_VERSION; }
 
+const char* molann_build_kind(void) {
+#ifdef MOLANN_DIAGNOSTICS
+    return "diagnostics";
+#else
+    return "release";
+#endif
+}
+
 const char* molann_error_string(int code) {
     switch (code) {
     case MOLANN_OK: return "ok";
@@ -1777,6 +1806,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     molann_plan* p = new (std::nothrow) molann_plan();
     if (!p) return (int)hipErrorOutOfMemory;
     memset(p, 0, sizeof(*p));
+    p->launch_mu = new std::mutex();
     p->device = dev;
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     p->n_inp = d->n_inp;
@@ -1817,7 +1847,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->n_slots = (int)slots.size();
     // (plan creation is setup time: MOLANN_DEBUG_NO_REGS / MOLANN_NO_JIT select the other generic modes here)
     p->regs_mode = p->n_items > 0 && p->n_items <= 64 && p->n_slots <= 16 && align_is_prefix &&
-                   getenv("MOLANN_DEBUG_NO_REGS") == nullptr;
+                   getenv("MOLANN_NO_REGS") == nullptr;
     memset(p->geom, 0, sizeof(p->geom));
     const bool lane_tables_fit = d->n_align <= 64 && (long)d->n_inp * 768 <= 65536;
     if (p->n_items > 0 && lane_tables_fit && cols_needed <= LANE_MAX_COLS)
@@ -1981,6 +2011,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         for (int h = 0; h < 2 && e == hipSuccess; ++h) {
             e = hipEventCreateWithFlags(&p->ev_feat[h], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_mlp[h], hipEventDisableTiming);
+            if (e == hipSuccess && h == 0) e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming);
         }
         if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     }
@@ -2012,7 +2043,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         const bool frame_ok = p->jit_geom.ok && 3 * d->n_inp >= 4;
         const long lds_waves = frame_ok ? (long)j.wpb * (163840 / ((long)j.wpb * j.lds_per_wave)) : 0;
         int waves0 = 2;
-        if (const char* e = getenv("MOLANN_DEBUG_JIT_WAVES")) waves0 = (atoi(e) >= 3 && lds_waves >= 12) ? 3 : 2;
+        if (const char* e = diag_env("MOLANN_DEBUG_JIT_WAVES")) waves0 = (atoi(e) >= 3 && lds_waves >= 12) ? 3 : 2;
         for (int waves = waves0; frame_ok && waves >= 2 && !p->jit_fn; --waves) {
             j.waves_per_eu = waves;
             std::vector<char> code;
@@ -2080,8 +2111,10 @@ int molann_plan_destroy(molann_plan* p) {
     if (p->side) {
         (void)hipStreamSynchronize(p->side);
         for (int h = 0; h < 2; ++h) { (void)hipEventDestroy(p->ev_feat[h]); (void)hipEventDestroy(p->ev_mlp[h]); }
+        (void)hipEventDestroy(p->ev_done);
         (void)hipStreamDestroy(p->side);
     }
+    delete p->launch_mu;
     hipError_t e = hipFree(p->blob);
     delete p;
     return (int)e;
@@ -2198,22 +2231,32 @@ int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, 
     char info[256];
     info[0] = 0;
     hipStream_t main = (hipStream_t)stream;
-    int i = 0;
-    for (int64_t s = 0; s < n; s += p->work_frames, ++i) {
+    std::lock_guard<std::mutex> lock(*p->launch_mu);
+    if (p->have_done && p->last_stream != main) HIP_TRY(hipStreamWaitEvent(main, p->ev_done, 0)); // another stream used the workspace last
+    int i = 0, rc = MOLANN_OK;
+    bool mlp_recorded[2] = {false, false};
+    for (int64_t s = 0; s < n && rc == MOLANN_OK; s += p->work_frames, ++i) {
         const int h = i & 1;
         const long m = (long)std::min<int64_t>(p->work_frames, n - s);
         float* work = p->d_work + (size_t)h * p->work_frames * p->d_feat;
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(main, p->ev_mlp[h], 0)); // this half is free again
-        int e = launch_pre(p, x + s * (long)p->n_inp * 3, m, work, 0, false, main);
-        if (e != 0) return e;
+        if (i >= 2 && (rc = (int)hipStreamWaitEvent(main, p->ev_mlp[h], 0)) != 0) break; // this half is free again
+        if ((rc = launch_pre(p, x + s * (long)p->n_inp * 3, m, work, 0, false, main)) != 0) break;
         if (s == 0) snprintf(info, sizeof(info), "%s", p->last_info);
-        HIP_TRY(hipEventRecord(p->ev_feat[h], main));
-        HIP_TRY(hipStreamWaitEvent(p->side, p->ev_feat[h], 0));
-        e = launch_mlp(p, work, m, p->d_feat, out + s * (long)p->out_dim, p->side);
-        if (e != 0) return e;
-        HIP_TRY(hipEventRecord(p->ev_mlp[h], p->side));
+        if ((rc = (int)hipEventRecord(p->ev_feat[h], main)) != 0) break;
+        if ((rc = (int)hipStreamWaitEvent(p->side, p->ev_feat[h], 0)) != 0) break;
+        rc = launch_mlp(p, work, m, p->d_feat, out + s * (long)p->out_dim, p->side);
+        const int er = (int)hipEventRecord(p->ev_mlp[h], p->side); // also behind a failed launch: the join below needs it
+        if (er == 0) mlp_recorded[h] = true;
+        if (rc == 0) rc = er;
     }
-    for (int h = 0; h < 2 && h < i; ++h) HIP_TRY(hipStreamWaitEvent(main, p->ev_mlp[h], 0)); // join
+    // join - on the error paths too: whatever reached the side stream is ordered before the caller's next work
+    for (int h = 0; h < 2; ++h)
+        if (mlp_recorded[h]) {
+            const int er = (int)hipStreamWaitEvent(main, p->ev_mlp[h], 0);
+            if (rc == 0) rc = er;
+        }
+    if (hipEventRecord(p->ev_done, main) == hipSuccess) { p->have_done = true; p->last_stream = main; }
+    if (rc != MOLANN_OK) return rc;
     snprintf(p->last_info, sizeof(p->last_info), "%.130s || %.90s chunk=%ld", info, p->mlp_info, p->work_frames);
     return MOLANN_OK;
 }

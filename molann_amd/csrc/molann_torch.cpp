@@ -10,13 +10,20 @@
 //                          Tensor grad_out, bool need_x, bool need_params) -> Tensor[]
 //
 // `desc` is everything the modules fix at construction time, as integers (layout below; written by
-// molann_amd/script.py).  Plans are created on first use and cached per (desc, device).  The live tensors
-// (ref_x buffer, Linear parameters) are re-read whenever their storage or version counter changes, as in
-// molann_amd/ann.py.  Only the HIP dispatch key is registered: a CPU tensor raises, there is no fallback.
+// molann_amd/script.py).  Plans are created on first use and cached per (desc, device); desc carries an
+// instance id, so two models of the same architecture have plans (packed weights, workspaces) of their own.
+// The live tensors (ref_x buffer, Linear parameters) are re-read whenever one of them is a different tensor
+// OBJECT than the one packed last (identity through a weak reference to its TensorImpl: an address the
+// allocator hands out again after a model was freed cannot pass for the old tensor), or its storage or version
+// counter changed.  The one edit this cannot see is an in-place write through `.data` / under a detached alias
+// (it bumps the alias's counter): molann::invalidate(desc, device) - `model.refresh_parameters()` in Python -
+// or MOLANN_ALWAYS_REPACK=1 covers that.  Entries are evicted least-recently-used beyond
+// MOLANN_PLAN_CACHE_SIZE (default 64) and by molann::release / molann::drop_plans.
+// Only the HIP dispatch key is registered: a CPU tensor raises, there is no fallback.
 // A libtorch host loads this library (dlopen / torch.ops.load_library) before torch::jit::load.
 //
-// desc: [0]=1 (layout version) [1]=kind (0 align, 1 features, 2 features+MLP) [2]=n_inp [3]=n_align
-//       [4]=n_features [5]=use_angle_value [6]=n_layers [7]=activation [8]=mlp_precision, then
+// desc: [0]=2 (layout version) [1]=kind (0 align, 1 features, 2 features+MLP) [2]=n_inp [3]=n_align
+//       [4]=n_features [5]=use_angle_value [6]=n_layers [7]=activation [8]=mlp_precision [9]=instance id, then
 //       align_idx[n_align], feat_type[n_features], feat_ptr[n_features+1], feat_idx[feat_ptr[n_features]],
 //       layer_dims[n_layers+1] (only when n_layers > 0)
 
@@ -38,21 +45,36 @@
 
 namespace {
 
-enum { KIND_ALIGN = 0, KIND_FEATURES = 1, KIND_FORWARD = 2, DESC_HEAD = 9 };
+enum { KIND_ALIGN = 0, KIND_FEATURES = 1, KIND_FORWARD = 2, DESC_LAYOUT = 2, DESC_HEAD = 10 };
 
+// What was packed: the tensor OBJECT (a weak reference keeps the TensorImpl's address from being reused while we
+// remember it, and says when the tensor is gone), its storage address and its version counter.
 struct TensorKey {
+    c10::weak_intrusive_ptr<c10::TensorImpl> impl{c10::weak_intrusive_ptr<c10::TensorImpl>(
+        c10::intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>())};
     const void* ptr = nullptr;
-    int64_t version = 0;
-    bool operator!=(const TensorKey& o) const { return ptr != o.ptr || version != o.version; }
+    int64_t version = -1;
+    bool matches(const at::Tensor& t) const {
+        return version >= 0 && !impl.expired() && impl._unsafe_get_target() == t.unsafeGetTensorImpl() && ptr == t.data_ptr() &&
+               version == (int64_t)t._version();
+    }
 };
 
-TensorKey key_of(const at::Tensor& t) { return {t.data_ptr(), t._version()}; }
+TensorKey key_of(const at::Tensor& t) {
+    TensorKey k;
+    k.impl = c10::weak_intrusive_ptr<c10::TensorImpl>(t.getIntrusivePtr());
+    k.ptr = t.data_ptr();
+    k.version = (int64_t)t._version();
+    return k;
+}
 
 struct Entry {
     molann_plan* plan = nullptr;
     int kind = 0, n_inp = 0, n_align = 0, n_layers = 0, out_dim = 0, feature_dim = 0;
     TensorKey ref_key;
     std::vector<TensorKey> mlp_key;
+    bool dirty = false; // molann::invalidate: repack at the next call whatever the keys say
+    uint64_t last_use = 0;
     std::mutex mu; // update_* + launch of one plan are one critical section
     ~Entry() {
         if (plan) molann_plan_destroy(plan);
@@ -70,7 +92,7 @@ struct Parsed {
 
 // the integer list -> molann_plan_desc (pointers into `p`)
 void parse_desc(const std::vector<int64_t>& v, Parsed& p) {
-    TORCH_CHECK(v.size() >= DESC_HEAD && v[0] == 1, "molann::run: unknown descriptor layout");
+    TORCH_CHECK(v.size() >= DESC_HEAD && v[0] == DESC_LAYOUT, "molann::run: unknown descriptor layout");
     const int64_t n_align = v[3], n_feat = v[4], n_layers = v[6];
     TORCH_CHECK(n_align >= 0 && n_feat >= 0 && n_layers >= 0 && n_layers <= MOLANN_MAX_LAYERS, "molann::run: bad descriptor counts");
     size_t pos = DESC_HEAD;
@@ -102,14 +124,41 @@ void parse_desc(const std::vector<int64_t>& v, Parsed& p) {
     d.mlp_precision = (int32_t)v[8];
 }
 
+typedef std::pair<std::vector<int64_t>, int> CacheKey;
 std::mutex g_cache_mu;
-std::map<std::pair<std::vector<int64_t>, int>, std::shared_ptr<Entry>> g_cache;
+std::map<CacheKey, std::shared_ptr<Entry>> g_cache;
+uint64_t g_clock = 0;
 
-// molann_plan_create reads two switches from the environment (MOLANN_NO_JIT, MOLANN_DEBUG_NO_REGS: which kernel
+size_t cache_capacity() {
+    static const size_t cap = [] {
+        const char* e = getenv("MOLANN_PLAN_CACHE_SIZE");
+        const long v = e ? atol(e) : 64;
+        return (size_t)(v < 1 ? 1 : v);
+    }();
+    return cap;
+}
+
+bool always_repack() {
+    static const bool v = [] { const char* e = getenv("MOLANN_ALWAYS_REPACK"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// caller holds g_cache_mu.  An evicted entry that a running call still holds lives until that call returns
+// (shared_ptr); its plan and device memory go with the last reference.
+void evict_lru_locked() {
+    while (g_cache.size() > cache_capacity()) {
+        auto victim = g_cache.begin();
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+            if (it->second->last_use < victim->second->last_use) victim = it;
+        g_cache.erase(victim);
+    }
+}
+
+// molann_plan_create reads two switches from the environment (MOLANN_NO_JIT, MOLANN_NO_REGS: which kernel
 // family serves the plan); a plan built under other settings must not be handed out, so they are part of the key
 int cache_device_key(int device) {
     const char* a = getenv("MOLANN_NO_JIT");
-    const char* b = getenv("MOLANN_DEBUG_NO_REGS");
+    const char* b = getenv("MOLANN_NO_REGS");
     return device | ((a && a[0] == '1') ? 1 << 16 : 0) | ((b && b[0] == '1') ? 1 << 17 : 0);
 }
 
@@ -118,7 +167,10 @@ std::shared_ptr<Entry> entry_for(const std::vector<int64_t>& desc, const at::Ten
     const auto key = std::make_pair(desc, cache_device_key((int)x.get_device()));
     std::lock_guard<std::mutex> lock(g_cache_mu);
     auto it = g_cache.find(key);
-    if (it != g_cache.end()) return it->second;
+    if (it != g_cache.end()) {
+        it->second->last_use = ++g_clock;
+        return it->second;
+    }
     Parsed p;
     parse_desc(desc, p);
     at::Tensor ref_host;
@@ -135,7 +187,9 @@ std::shared_ptr<Entry> entry_for(const std::vector<int64_t>& desc, const at::Ten
     e->n_layers = p.d.n_layers;
     e->out_dim = molann_plan_out_dim(e->plan);
     e->feature_dim = molann_plan_feature_dim(e->plan);
+    e->last_use = ++g_clock;
     g_cache.emplace(key, e);
+    evict_lru_locked();
     return e;
 }
 
@@ -164,19 +218,17 @@ void sync_live(Entry& e, const at::Tensor& x, const at::Tensor& ref_x, const std
                const std::vector<at::Tensor>& biases, hipStream_t stream) {
     if (e.n_align > 0) {
         const at::Tensor r = device_f32(ref_x.detach(), x, "ref_x");
-        const TensorKey k = key_of(ref_x);
-        if (k != e.ref_key) {
+        if (e.dirty || always_repack() || !e.ref_key.matches(ref_x)) {
             check(molann_plan_update_ref(e.plan, r.data_ptr<float>(), stream), "molann_plan_update_ref");
-            e.ref_key = k;
+            e.ref_key = key_of(ref_x);
         }
     }
     if (e.kind == KIND_FORWARD) {
         TORCH_CHECK((int)weights.size() == e.n_layers && (int)biases.size() == e.n_layers,
                     "molann::run: expected ", e.n_layers, " weight and bias tensors");
-        std::vector<TensorKey> k;
-        for (int l = 0; l < e.n_layers; ++l) { k.push_back(key_of(weights[l])); k.push_back(key_of(biases[l])); }
-        bool changed = k.size() != e.mlp_key.size();
-        for (size_t i = 0; !changed && i < k.size(); ++i) changed = k[i] != e.mlp_key[i];
+        bool changed = e.dirty || always_repack() || e.mlp_key.size() != 2 * (size_t)e.n_layers;
+        for (int l = 0; !changed && l < e.n_layers; ++l)
+            changed = !e.mlp_key[2 * l].matches(weights[l]) || !e.mlp_key[2 * l + 1].matches(biases[l]);
         if (changed) {
             std::vector<at::Tensor> hold;
             std::vector<const float*> W, B;
@@ -187,9 +239,11 @@ void sync_live(Entry& e, const at::Tensor& x, const at::Tensor& ref_x, const std
                 B.push_back(hold.back().data_ptr<float>());
             }
             check(molann_plan_update_mlp(e.plan, W.data(), B.data(), stream), "molann_plan_update_mlp");
-            e.mlp_key = k;
+            e.mlp_key.clear();
+            for (int l = 0; l < e.n_layers; ++l) { e.mlp_key.push_back(key_of(weights[l])); e.mlp_key.push_back(key_of(biases[l])); }
         }
     }
+    e.dirty = false;
 }
 
 void check_x(const at::Tensor& x, const std::vector<int64_t>& desc) {
@@ -265,6 +319,47 @@ std::string launch_info(std::vector<int64_t> desc, int64_t device) {
     return buf;
 }
 
+// every cached plan derived from this description on this device (the plan itself, its features-only and
+// alignment-as-features variants share the head up to the instance id)
+template <typename F>
+void for_plans_of(const std::vector<int64_t>& desc, int64_t device, F f) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (auto it = g_cache.begin(); it != g_cache.end();) {
+        const std::vector<int64_t>& d = it->first.first;
+        const bool same_dev = (it->first.second & 0xffff) == (int)device;
+        const bool same_model = d.size() >= DESC_HEAD && desc.size() >= DESC_HEAD && d[9] == desc[9] && d[2] == desc[2] &&
+                                (d == desc || desc[9] != 0);
+        if (same_dev && same_model) it = f(it);
+        else ++it;
+    }
+}
+
+// the live tensors of this model were written in a way their version counters do not show (`.data`): repack
+void invalidate(std::vector<int64_t> desc, int64_t device) {
+    for_plans_of(desc, device, [](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) {
+        std::lock_guard<std::mutex> lock(it->second->mu);
+        it->second->dirty = true;
+        return ++it;
+    });
+}
+
+// the model is gone: give its plans (device blobs, workspaces, code objects) back
+void release(std::vector<int64_t> desc, int64_t device) {
+    for_plans_of(desc, device, [](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) { return g_cache.erase(it); });
+}
+
+int64_t drop_plans() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    const int64_t n = (int64_t)g_cache.size();
+    g_cache.clear();
+    return n;
+}
+
+int64_t cached_plans() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return (int64_t)g_cache.size();
+}
+
 at::Tensor call_run(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
                     const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases) {
     static auto op = c10::Dispatcher::singleton()
@@ -302,6 +397,12 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        // grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these
+        // gradients again (the reference can, through plain autograd).  molann_backward_f32 is a kernel, its result has
+        // no graph: refusing is the only honest answer - silently returning constants would drop terms of a loss.
+        TORCH_CHECK(!at::GradMode::is_enabled(),
+                    "molann::run: the backward kernel is first-order only; create_graph=True (double backward, e.g. a loss on "
+                    "forces) is not supported");
         const auto saved = ctx->get_saved_variables();
         const std::vector<int64_t> desc = ctx->saved_data["desc"].toIntVector();
         const int64_t nl = ctx->saved_data["n_layers"].toInt();
@@ -392,6 +493,10 @@ TORCH_LIBRARY(molann, m) {
     m.def("run_backward(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, bool need_x, "
           "bool need_params) -> Tensor[]");
     m.def("launch_info(int[] desc, int device) -> str", launch_info);
+    m.def("invalidate(int[] desc, int device) -> ()", invalidate);
+    m.def("release(int[] desc, int device) -> ()", release);
+    m.def("drop_plans() -> int", drop_plans);
+    m.def("cached_plans() -> int", cached_plans);
 }
 
 TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP device "cuda"

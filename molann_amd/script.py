@@ -29,8 +29,15 @@ from . import _capi
 TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmolann_torch.so")
 
 KIND_ALIGN, KIND_FEATURES, KIND_FORWARD = 0, 1, 2
-_DESC_LAYOUT = 1
+_DESC_LAYOUT = 2
 _loaded = False
+
+
+def new_instance_id():
+    """A process-unique, practically world-unique id for one model: plans (packed weights, workspaces) are cached per
+    description, and two models of the same architecture must not share one."""
+    import random
+    return random.SystemRandom().getrandbits(62) | 1
 
 
 def load_ops():
@@ -46,7 +53,7 @@ def load_ops():
 
 
 def make_desc(kind, n_inp, align_idx=None, features=None, use_angle_value=False, layer_dims=None,
-              activation=_capi.ACT_TANH, mlp_precision=_capi.MLP_F32):
+              activation=_capi.ACT_TANH, mlp_precision=_capi.MLP_F32, instance=None):
     """The integer list ``molann::run`` builds its plan from (layout: `csrc/molann_torch.cpp`).
     ``features`` is ``[(type_id, [local atom indices]), ...]`` in output-column order."""
     align_idx = [int(i) for i in (align_idx or [])]
@@ -54,7 +61,7 @@ def make_desc(kind, n_inp, align_idx=None, features=None, use_angle_value=False,
     layer_dims = [int(d) for d in (layer_dims or [])]
     n_layers = len(layer_dims) - 1 if layer_dims else 0
     desc = [_DESC_LAYOUT, int(kind), int(n_inp), len(align_idx), len(features), 1 if use_angle_value else 0,
-            n_layers, int(activation), int(mlp_precision)]
+            n_layers, int(activation), int(mlp_precision), int(new_instance_id() if instance is None else instance)]
     desc += align_idx
     desc += [int(t) for t, _ in features]
     if features:

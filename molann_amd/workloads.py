@@ -156,7 +156,7 @@ def chain_features(n_atoms, n_features, seed):
 def _c1():
     return Workload("C1", ALA_DIPEPTIDE_XYZ, [(BOND, (5, 6)), (DIHEDRAL, (1, 3, 2, 4))],
                     mlp_dims=[3, 5, 3], frames=1024,
-                    description="22 atoms, bond 5-6 + dihedral 1-3-2-4 (literal order), MLP [3,5,3], 1024 frames")
+                    description="22 atoms, bond 5-6 + dihedral 1-3-2-4 (literal order), MLP [3,5,3]")
 
 
 def _c1_sorted():
@@ -167,14 +167,14 @@ def _c1_sorted():
 
 def _c2():
     return Workload("C2", ALA_DIPEPTIDE_XYZ, [(BOND, (5, 6)), (DIHEDRAL, (1, 3, 2, 4))],
-                    frames=1 << 20, description="22 atoms, FeatureLayer only (2 features, d=3), 1M frames")
+                    frames=1 << 20, description="22 atoms, FeatureLayer only (2 features, d=3)")
 
 
 def _c3():
     feats = [(DIHEDRAL, (5, 7, 9, 15)), (DIHEDRAL, (7, 9, 15, 17)), (BOND, (5, 6)), (ANGLE, (16, 15, 17))]
     return Workload("C3", ALA_DIPEPTIDE_XYZ, feats, align=ALA_BACKBONE, mlp_dims=[6, 32, 8],
                     frames=1 << 20, rigid_motion=True,
-                    description="22 atoms, Kabsch on 7 backbone atoms + 4 features (d=6) + MLP [6,32,8], 1M frames")
+                    description="22 atoms, Kabsch on 7 backbone atoms + 4 features (d=6) + MLP [6,32,8]")
 
 
 def _c3p():
@@ -188,7 +188,7 @@ def _c4():
     align = tuple(range(9, 5001, 16))
     return Workload("C4", xyz, chain_features(5000, 64, 41), align=align, mlp_dims=[85, 128, 64, 8],
                     frames=1 << 19,
-                    description="5000-atom chain, Kabsch on 312 'CA' + 64 features (d=85) + MLP [85,128,64,8], 512k frames/GPU")
+                    description="5000-atom chain, Kabsch on 312 'CA' + 64 features (d=85) + MLP [85,128,64,8]")
 
 
 def _c5():
@@ -196,7 +196,7 @@ def _c5():
     align = tuple(range(9, 5001, 16))
     return Workload("C5", xyz, chain_features(5000, 256, 42), align=align, mlp_dims=[341, 512, 256, 16],
                     frames=1 << 20, mlp_dtype="bf16",
-                    description="5000-atom chain, Kabsch on 312 'CA' + 256 features (d=341) + bf16 MLP [341,512,256,16], 1M frames/GPU")
+                    description="5000-atom chain, Kabsch on 312 'CA' + 256 features (d=341) + bf16 MLP [341,512,256,16]")
 
 
 def _a3():

@@ -243,7 +243,7 @@ def test_capi_direct_forward_f32(hip_device):
                                         ctypes.c_void_p(out.data_ptr()), plan._stream()) == _capi.E_STAGE
 
 
-@pytest.mark.parametrize("env", [{"MOLANN_NO_JIT": "1"}, {"MOLANN_NO_JIT": "1", "MOLANN_DEBUG_NO_REGS": "1"}],
+@pytest.mark.parametrize("env", [{"MOLANN_NO_JIT": "1"}, {"MOLANN_NO_JIT": "1", "MOLANN_NO_REGS": "1"}],
                          ids=["generic_regs", "generic_lds"])
 @pytest.mark.parametrize("name", ["molann_C1", "molann_C3", "features_C2", "features_C3p", "features_C3_val",
                                   "flayer_permuted_input", "pp_align123_pos12", "molann_C3_relu", "molann_C3_sigmoid"])
@@ -257,7 +257,7 @@ def test_generic_lane_kernels(name, env, hip_device, monkeypatch):
     pp = model if c.kind == "features" else model.preprocessing_layer
     info = last_launch_info(model if c.kind != "features" else pp)
     assert "frames_lane_kernel" in info, info
-    assert ("features_lds" in info) == ("MOLANN_DEBUG_NO_REGS" in env) or "features_regs" not in info
+    assert ("features_lds" in info) == ("MOLANN_NO_REGS" in env) or "features_regs" not in info
     assert float((got - c.out_f32).abs().max()) <= c.tolerance_vs_f32()
 
 

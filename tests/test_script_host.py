@@ -32,9 +32,12 @@ def test_op_library_loads_and_registers_both_operators():
 
 def test_make_desc_layout():
     d = script.make_desc(script.KIND_FORWARD, 22, align_idx=[1, 4], features=[(2, [0, 2, 1, 3]), (1, [4, 5])],
-                         use_angle_value=True, layer_dims=[2, 5, 3], activation=1, mlp_precision=0)
-    assert d == [1, 2, 22, 2, 2, 1, 2, 1, 0, 1, 4, 2, 1, 0, 4, 6, 0, 2, 1, 3, 4, 5, 2, 5, 3]
-    assert script.make_desc(script.KIND_ALIGN, 5, align_idx=[0, 1, 4]) == [1, 0, 5, 3, 0, 0, 0, 0, 0, 0, 1, 4]
+                         use_angle_value=True, layer_dims=[2, 5, 3], activation=1, mlp_precision=0, instance=77)
+    assert d == [2, 2, 22, 2, 2, 1, 2, 1, 0, 77, 1, 4, 2, 1, 0, 4, 6, 0, 2, 1, 3, 4, 5, 2, 5, 3]
+    assert script.make_desc(script.KIND_ALIGN, 5, align_idx=[0, 1, 4], instance=5) == [2, 0, 5, 3, 0, 0, 0, 0, 0, 5, 0, 1, 4]
+    # two models of one architecture get descriptions (= cached plans, packed weights, workspaces) of their own
+    a, b = (script.make_desc(script.KIND_ALIGN, 5, align_idx=[0, 1, 4]) for _ in range(2))
+    assert a[9] != b[9] and a[:9] == b[:9] and a[10:] == b[10:]
 
 
 def _reference_test_modules():
@@ -81,7 +84,7 @@ def test_scripted_model_shares_parameters_and_keeps_reference_buffer():
     assert s.linears[0].weight.data_ptr() == lin0.weight.data_ptr()
     assert torch.equal(s.ref_x, m.preprocessing_layer.align_layer.ref_x)
     assert list(s.state_dict().keys()) == ['ref_x', 'linears.0.weight', 'linears.0.bias', 'linears.1.weight', 'linears.1.bias']
-    assert s.desc[:9] == [1, script.KIND_FORWARD, 22, 7, 4, 0, 2, 0, 0]
+    assert s.desc[:9] == [2, script.KIND_FORWARD, 22, 7, 4, 0, 2, 0, 0] and s.desc[9] != 0
 
 
 def test_unrecognised_ann_layers_script_as_a_chain():
