@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # measured float4 copy (same guide)
 
 # variables that change WHAT is computed (or skip part of it): a line measured under one is not a result
-RESULT_CHANGING_ENV = ("MOLANN_ELIDE_INVARIANT_ALIGNMENT", "MOLANN_DEBUG_")
+RESULT_CHANGING_ENV = ("MOLANN_ELIDE_INVARIANT_ALIGNMENT", "MOLANN_DEBUG_", "MOLANN_DIAG_LIB", "MOLANN_JIT_EXTRA_FLAGS")
 
 
 def parse_args(argv=None):
@@ -221,6 +221,10 @@ class HipSide(object):
     def kernels(self, model):
         from molann_amd.ann import last_launch_info
         return last_launch_info(model)
+
+    def library(self):
+        from molann_amd import _capi
+        return _capi.build_kind()      # "release": the product library reads no result-changing switch
 
 
 def host_cores():
@@ -428,7 +432,7 @@ def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, e
                        "n_atoms": w.n_atoms, "align_atoms": len(w.align) if w.align else 0,
                        "features": len(w.features), "feature_dim": w.feature_dim(),
                        "mlp": w.mlp_dims, "input_buffers": nbuf, "parallelism": "frames sharded x%d" % world,
-                       "final_allgather": bool(gather), "kernels": side.kernels(model),
+                       "final_allgather": bool(gather), "kernels": side.kernels(model), "library": side.library(),
                        "env": env if env is not None else molann_env(),
                        "dist": {"world_size": dist.get_world_size() if distributed else 1,
                                 "backend": dist.get_backend() if distributed else None,

@@ -188,9 +188,9 @@ int molann_plan_last_launch_info(const molann_plan* plan, char* buf, int cap);
  * Returns the source length; on a compile failure a positive hiprtcResult and the log in buf. */
 int molann_debug_jit(const molann_plan_desc* desc, int do_compile, char* buf, int cap);
 
-/* Diagnostic: per-phase shader-clock sums recorded when MOLANN_DEBUG_ABLATE has bit 32 set (see
- * tools/stamps.py); reads and clears 8 counters.  Synchronises the device: never on a product path. */
-int molann_debug_read_stamps(unsigned long long* out8);
+/* Diagnostic (diagnostics build only): per-phase shader-clock sums recorded when MOLANN_DEBUG_ABLATE has bit 32
+ * set (see tools/stamps.py); reads and clears 16 counters.  Synchronises the device: never on a product path. */
+int molann_debug_read_stamps(unsigned long long* out16);
 
 /* Self-test hooks: the __host__ __device__ math the kernels are built from, compiled for the HOST, so
  * the CPU test-suite can check it against the oracle without a GPU.  Not a product path. */

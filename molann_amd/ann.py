@@ -92,6 +92,10 @@ _RUN_OP = []
 def _run_op():
     """``torch.ops.molann.run`` if csrc/libmolann_torch.so has been built, else None (then ctypes serves every call)."""
     if not _RUN_OP:
+        import os
+        if os.environ.get("MOLANN_DIAG_LIB") == "1":   # tools/ on the diagnostics build: the operator library is
+            _RUN_OP.append(None)                        # linked against the release build, so ctypes serves every call
+            return None
         try:
             from . import script
             script.load_ops()
@@ -156,8 +160,14 @@ class _PlanFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable   # the backward is a kernel: first-order only, and it says so
     def backward(ctx, grad_out):
+        # Grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these
+        # gradients again (the reference can, through plain autograd incl. its SVD).  The kernel's result has no graph,
+        # and `once_differentiable` would not notice either (the dependence runs through the saved x and parameters,
+        # not through grad_out) - so refuse, rather than silently drop terms of a loss built on forces.
+        if torch.is_grad_enabled():
+            raise RuntimeError("molann_amd: the backward kernel is first-order only; create_graph=True (double "
+                               "backward, e.g. a loss on forces) is not supported")
         (x,) = ctx.saved_tensors
         plan = ctx.entry.plan
         need_x = ctx.needs_input_grad[0]

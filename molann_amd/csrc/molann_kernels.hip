@@ -192,7 +192,7 @@ __device__ __forceinline__ void activate(int act, float (&h)[W]) {
 // added to this array by lane 0 at kernel end and read back by molann_debug_read_stamps.  Shares of a
 // wave's time, not a timing of the production kernel (the stamps drain LDS/scalar queues).
 // ---------------------------------------------------------------------------------------------
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];
 
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -1018,6 +1018,61 @@ __global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
     }
 }
 
+// ---- 4x4x1 image (specialised lane kernel, MLP_MODE 1) ---------------------------------------------------------
+// v_mfma_f32_4x4x1_16b_f32 keeps each of its 16 blocks inside 4 lanes: D_b[i][j] += A_b[i] * B_b[j], A_b[i] read
+// from lane 4b+i, B_b[j] from lane 4b+j, D_b[i][j] written to VGPR i of lane 4b+j (tools/micro/mfma4x4.hip).  With
+// lane = frame, B = the lane's own input k and A = four weights W[4g..4g+3][k] repeated over the blocks, every lane
+// gets units 4g..4g+3 of ITS OWN frame: a per-lane matrix-vector product with shared weights, no transposition
+// through LDS and no padding beyond the next multiple of four units.  One A operand per (layer, input k, unit group
+// g), k = K_l being the bias (its B operand is the constant 1):  operand r = base_l + k G_l + g, lane L =
+// Wf_l[4g + L%4][k].  The image is stored as quads of operands interleaved per lane ([r / 4][lane][r % 4]) so that a
+// consumer wave fetches four operands with one conflict-free ds_read_b128 from the block's LDS copy: the operands
+// are consumed in this order and live in registers only while they are used (a whole image would cost C3 122 VGPRs
+// and two of every four waves a SIMD can hold).
+//
+// Wf folds what is affine around the activation into the weights (exact in real arithmetic, rounded once here):
+// tanh and sigmoid are computed as r = 1 / (1 + 2^z') with z' = sigma z, and the next layer takes r itself:
+//   h = alpha + beta r   (tanh: alpha 1, beta -2, sigma 2 log2 e;  sigmoid: alpha 0, beta 1, sigma -log2 e)
+//   Wf_l = sigma_l beta_(l-1) W_l,   bf_l = sigma_l (b_l + alpha_(l-1) sum_k W_l[.,k]),
+// sigma_l = sigma for layers followed by the activation, 1 for the last; alpha_(-1) = 0, beta_(-1) = 1.  Other
+// activations: alpha 0, beta 1, sigma 1 (the kernel applies them as they are).  Two instructions per hidden unit
+// (v_exp, v_rcp + one add) instead of five.
+__host__ __device__ inline int mlp4_groups(int J) { return (J + 3) / 4; }
+inline int mlp4_regs(const int* dims, int nl) {
+    int r = 0;
+    for (int l = 0; l < nl; ++l) r += mlp4_groups(dims[l + 1]) * (dims[l] + 1);
+    return r;
+}
+constexpr int MLP4_MAX_REGS = 256;   // 64 quads: the ds_read offset field is 16 bits, and the image (<= 64 KiB) comes out of the ring's LDS
+
+__global__ void pack_lane4_kernel(float* __restrict__ dst, PackArgs p, int act, int total_regs) {
+    const double LOG2E = 1.4426950408889634;
+    const double alpha = act == 0 ? 1.0 : 0.0, beta = act == 0 ? -2.0 : 1.0;
+    const double sigma = act == 0 ? 2.0 * LOG2E : (act == 2 ? -LOG2E : 1.0);
+    const int padded = (total_regs + 3) & ~3;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < padded * 64; e += gridDim.x * blockDim.x) {
+        const int lane = (e >> 2) & 63;
+        int r = ((e >> 8) << 2) | (e & 3), l = 0;          // element e = [r / 4][lane][r % 4]
+        if (r >= total_regs) { dst[e] = 0.f; continue; }
+        while (l < p.n_layers && r >= mlp4_groups(p.dims[l + 1]) * (p.dims[l] + 1)) { r -= mlp4_groups(p.dims[l + 1]) * (p.dims[l] + 1); ++l; }
+        const int K = p.dims[l], J = p.dims[l + 1], G = mlp4_groups(J);
+        const int k = r / G, g = r - k * G;
+        const int u = 4 * g + (lane & 3);
+        const double sl = l + 1 < p.n_layers ? sigma : 1.0;
+        const double a_in = l > 0 ? alpha : 0.0, b_in = l > 0 ? beta : 1.0;
+        double v = 0.0;
+        if (u < J) {
+            if (k < K) v = sl * b_in * (double)p.W[l][(long)u * K + k];
+            else {
+                double sw = 0.0;
+                for (int kk = 0; kk < K; ++kk) sw += (double)p.W[l][(long)u * K + kk];
+                v = sl * ((double)p.b[l][u] + a_in * sw);
+            }
+        }
+        dst[e] = (float)v;
+    }
+}
+
 // mfma layout, layer l: Wp[Jp][Kp] (zero padded; fp32 or bf16) then bias[Jp] (fp32)
 __global__ void pack_mfma_kernel(void* __restrict__ dst_v, PackArgs p) {
     const int l = blockIdx.y;
@@ -1210,6 +1265,8 @@ struct molann_plan {
     double* d_ref64;   // the same in fp64 (covariance accumulation)
     ItemDev* d_items;
     float* d_wlane;    // fused layout
+    float* d_wlane4;   // 4x4x1 image of the specialised kernel's lane-local MLP (mlp4_regs registers x 64 lanes)
+    int mlp4_regs;     // 0: that kernel runs the 16x16x4 chained MLP from d_wlane
     void* d_wmfma;     // mfma layout
     float* d_work;     // two feature chunks [2][work_frames][d_feat] (ping-pong between gather and MLP kernels)
     long work_frames;
@@ -1234,6 +1291,7 @@ struct molann_plan {
     int jit_nl;          // Linear layers fused into it (0: features only)
     LaneGeom jit_geom;   // its own LDS geometry: the compact tile (touched 16-byte windows only) + staging columns
     int jit_waves;       // waves per SIMD it was compiled for
+    int jit_ncons, jit_nload, jit_nslot, jit_bpc, jit_lds_block; // loader / consumer block geometry of the specialised forward kernel
     bool jit_only;       // no ahead-of-time kernel serves this plan's fused forward (large frame / 33..64 features)
     char jit_note[96];
     struct JitSpecBox* spec;   // what the specialised kernels are generated from (kept for the lazy backward build)
@@ -1397,8 +1455,12 @@ std::string join_chunks(const char* const* chunks) {
 
 struct JitSpec { // what the specialised kernel is compiled for
     int n_inp, n_align, n_layers, act, d_feat, out_cols, wpb, lds_per_wave, fbuf_off;
-    int waves_per_eu = 2;             // occupancy the forward kernel is compiled for (amdgpu_waves_per_eu)
-    int nbuf = 1;                     // tile buffers per wave
+    int waves_per_eu = 2;             // occupancy the backward kernel is compiled for (amdgpu_waves_per_eu)
+    int nbuf = 1;
+    // forward kernel: loader / consumer block around a ring of tile slots (molann_lane_jit.inc)
+    int mlp_mode = 0;                 // 1: lane-local 4x4x1 MLP (weights from the plan's d_wlane4 image)
+    int nload = 1, w_bytes = 0, mlp4_regs = 0;   // loaders per block; bytes / operands of the lane-local MLP's LDS image
+    int ncons = 0, nslot = 0, depth = 0, ring_off = 0, tile_stride = 0, fb_off = 0, fb_bytes = 0, lds_block = 0, bpc = 0;
     std::vector<int> win;             // compact staging: first dword of each 16-byte window copied per frame
     std::vector<int> slots;           // slot -> atom
     std::vector<ItemDev> items;       // atoms as slot indices
@@ -1429,26 +1491,52 @@ std::vector<int> compact_windows(const std::vector<int>& slot_atoms, int n_inp) 
     return win;
 }
 
-// LDS geometry of the specialised kernel: the compact tile (x2 when 8 waves per CU still fit: a wave then has the
-// next tile resident while the one after it is in flight) + the feature staging rows (the fused MLP reads only the
-// real D_FEAT rows; padded k's are zeros in registers).
+// LDS geometry of the specialised forward kernel: per block a header of hand-off words, a ring of NSLOT compact
+// tiles and one feature staging buffer per consumer wave (the fused MLP reads only the real D_FEAT rows; padded k's
+// are zeros in registers).  A block is NCONS consumers + 1 loader; blocks <= 64 KiB (the LDS-DMA destination offset
+// is 16 bits).  Preference: 8 consumers per CU (two per SIMD: the arithmetic saturates the vector ALU there), then
+// the deepest ring, then the fewest blocks (= loader waves).
 void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fallback_cols) {
-    const int tile = 64 * 16 * (int)j.win.size();
-    const int fb = ceil_to(std::max(1, staging_rows) * FB_STRIDE * 4, 16);
-    const long L2 = 2l * tile + fb;
-    const char* nb = diag_env("MOLANN_DEBUG_JIT_NBUF"); // experiments: 2 = double-buffered tiles where they fit
-    if (nb && atoi(nb) == 2 && 2 * L2 <= 65536 && 8 * L2 <= 163840) { // blocks of 2 waves, 4 blocks per CU
-        g.wpb = 2; g.lds_per_wave = (int)L2; g.fbuf_off = 2 * tile; g.ok = 1;
-        j.nbuf = 2;
-    } else {
-        lane_geometry(g, tile, fallback_cols);
-        j.nbuf = 1;
-        // the kernel runs 2 (or 3) waves per SIMD = 8 (12) per CU: a block size that divides them
-        if (g.ok && g.wpb == 3) {
-            const long L = g.lds_per_wave;
-            g.wpb = (4 * L <= 65536 && 8 * L <= 163840) ? 4 : 2;
+    const int tile = ceil_to(64 * 16 * (int)j.win.size(), 16);
+    const int fb = staging_rows > 0 ? ceil_to(staging_rows * FB_STRIDE * 4, 16) : 0; // none: the lane-local MLP stages nothing
+    // One block per CU: 14 consumer waves + 2 loaders = four waves per SIMD (the kernel is built for <= 128 VGPRs).
+    // Two loaders because a wave has at most 63 vector-memory operations in flight (vmcnt) = 63 KB of tiles, and
+    // the loaded HBM latency (~4 us, tools/stamps.py) needs ~120 KB in flight per CU for 6 TB/s; the consumers beyond
+    // two per SIMD add no vector-ALU rate but keep the SIMD issuing while others wait (LDS, MFMA results, a tile).
+    j.bpc = 1;
+    j.ncons = 14;
+    j.nload = 2;
+    j.w_bytes = j.mlp_mode == 1 ? ((j.mlp4_regs + 3) / 4) * 1024 : 0;
+    const int header = 256 + j.w_bytes;
+    long nslot = 0;
+    auto fit = [&]() {
+        nslot = std::min<long>(16, (163840 / j.bpc - header - (long)j.ncons * fb) / tile);
+        return nslot >= 2 * j.nload || (j.ncons == 1 && nslot >= 1);
+    };
+    while (!fit() && j.ncons > 1) { --j.ncons; if (j.ncons < 4) j.nload = 1; }   // large tiles: fewer consumers, down to one
+    bool ok = fit();
+    if (const char* e = diag_env("MOLANN_DEBUG_LC")) { // experiments: "blocks per CU,consumers,slots,loaders"
+        int b = 0, c = 0, n = 0, ld = 1;
+        if (sscanf(e, "%d,%d,%d,%d", &b, &c, &n, &ld) >= 3 && b >= 1 && c >= 1 && c <= 15 && n >= 1 && n <= 16 && ld >= 1 && ld <= 4 &&
+            header + (long)n * tile + (long)c * fb <= 163840 / b) {
+            j.bpc = b; j.ncons = c; nslot = n; j.nload = ld; ok = true;
         }
     }
+    g.ok = ok ? 1 : 0;
+    if (!g.ok) { lane_geometry(g, tile, fallback_cols); g.ok = 0; return; }
+    j.nslot = (int)nslot;
+    const int nw = (int)j.win.size();
+    j.depth = std::min(6, 63 / std::max(1, nw));   // tiles a loader keeps in flight behind its newest published one: vmcnt <= 63
+    j.depth = std::min(j.depth, std::max(0, j.nslot / j.nload - 1));
+    if (const char* e = diag_env("MOLANN_DEBUG_LC_DEPTH")) j.depth = std::max(0, std::min(j.depth, atoi(e)));
+    j.ring_off = header;
+    j.tile_stride = tile;
+    j.fb_off = header + j.nslot * tile;
+    j.fb_bytes = fb;
+    j.lds_block = j.fb_off + j.ncons * fb;
+    j.nbuf = 1;
+    // (the fields of the older one-buffer-per-wave geometry stay filled: the backward kernel's preamble names them)
+    g.wpb = std::min(4, j.ncons); g.lds_per_wave = tile + std::max(fb, 16); g.fbuf_off = tile;
     j.wpb = g.wpb; j.lds_per_wave = g.lds_per_wave; j.fbuf_off = g.fbuf_off;
 }
 
@@ -1509,6 +1597,13 @@ std::string jit_preamble(const JitSpec& j) {
     K("NL", j.n_layers); K("ACT", j.act); K("D_FEAT", j.d_feat); K("OUT_COLS", j.out_cols); K("WPB", j.wpb);
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
     K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
+    K("NCONS", j.ncons); K("NLOAD", j.nload); K("LDS_BLOCK", j.lds_block); K("NSLOT", j.nslot); K("DEPTH", j.depth); K("RING_OFF", j.ring_off); K("TILE_STRIDE", j.tile_stride);
+    K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes); K("MLP_MODE", j.mlp_mode); K("W_OFF", 256); K("W_BYTES", j.w_bytes);
+    {   // waves per SIMD the forward kernel must fit (its register budget): every wave of the (NCONS + 1)-wave blocks
+        // a CU is to hold - the loader waves carry the consumers' allocation
+        const int waves = (j.ncons + j.nload) * std::max(1, j.bpc);
+        K("WAVES_FWD", std::max(1, std::min(8, (waves + 3) / 4)));
+    }
     {   // Opt-in, never used for a reported number: a plan whose items are all invariant under rigid motion produces the
         // same output with or without its alignment; MOLANN_ELIDE_INVARIANT_ALIGNMENT=1 (read at plan creation) drops
         // the (then dead) Kabsch from the specialised kernel.  Default: the alignment is computed, as the reference does.
@@ -1536,6 +1631,8 @@ std::string jit_preamble(const JitSpec& j) {
     s += (debug_env().ablate & 256) ? "constexpr bool SAME_TILE = true;\n" : "constexpr bool SAME_TILE = false;\n";
     // diagnostic (bit 512): the fused MLP's 16-byte output stores are (data-dependently) never executed
     s += (debug_env().ablate & 512) ? "constexpr bool NO_STORES = true;\n" : "constexpr bool NO_STORES = false;\n";
+    // diagnostic (bit 2048): consumers hand every tile back as soon as it is in registers and compute nothing
+    s += (debug_env().ablate & 2048) ? "constexpr bool NO_COMPUTE = true;\n" : "constexpr bool NO_COMPUTE = false;\n";
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
@@ -1563,7 +1660,7 @@ std::string jit_preamble(const JitSpec& j) {
 }
 
 // compile to a gfx950 code object; returns 0 or a hiprtcResult, log filled on failure
-int jit_compile(const std::string& src, std::vector<char>& code, std::string& log) {
+int jit_compile(const std::string& src, std::vector<char>& code, std::string& log, const char* more_flags = nullptr) {
     const RtcApi* rtc = rtc_api();
     if (!rtc->ok) { log = "libhiprtc.so not found"; return -1; }
     const std::string math = join_chunks(k_src_molann_math_h);
@@ -1573,6 +1670,7 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
     hiprtcResult r = rtc->create(&prog, src.c_str(), "molann_lane_jit.hip", 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return (int)r; }
     std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    if (more_flags && more_flags[0]) flags.push_back(more_flags);
     if (const char* extra = diag_env("MOLANN_JIT_EXTRA_FLAGS")) { // experiments: space-separated compiler flags
         std::string e(extra);
         size_t pos = 0;
@@ -1608,24 +1706,21 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
     fill_pre_args(p, a, n_frames, mode, out_cols, with_mlp, x, out);
     // the plan-specialised lane kernel first: it serves every plan it was built for, including few-atom plans on
     // frames too large for the ahead-of-time lane kernel's dense tile
-    if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
-        const molann_plan::LaneGeom& jg = p->jit_geom;
+    if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024 | 2048)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
         const long n_tiles = (n_frames + 63) / 64;
-        const int jwpb = jg.wpb;
-        int jbpc = (int)(163840 / ((long)jwpb * jg.lds_per_wave));
-        jbpc = std::max(1, std::min(jbpc, std::max(1, 4 * p->jit_waves / jwpb)));
-        const int jgrid = grid_for(p, n_tiles, jwpb, jbpc);
-        const size_t jlds = (size_t)jwpb * jg.lds_per_wave + (size_t)debug_env().lds_pad;
+        const int jgrid = grid_for(p, n_tiles, 1, p->jit_bpc);   // every block needs at least one tile
+        const size_t jlds = (size_t)debug_env().lds_pad;   // the kernel declares its block's LDS statically
         unsigned long long* stamps = nullptr;
         if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
         struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
-                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
+                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, (with_mlp && p->mlp4_regs > 0) ? p->d_wlane4 : p->d_wlane, n_frames, a.x_wide,
                                                                         a.out_vec4, stamps, p->d_ref};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-        const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, 64 * jwpb, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
-        snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised, %d waves/SIMD) grid=%d block=%d lds=%zu",
-                 p->jit_nl, p->jit_waves, jgrid, 64 * jwpb, jlds);
+        const int jblock = 64 * (p->jit_ncons + p->jit_nload);
+        const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, jblock, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
+        snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d",
+                 p->jit_nl, p->jit_ncons, p->jit_nload, p->jit_nslot, jgrid, jblock, p->jit_lds_block);
         return (int)le;
     }
     const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
@@ -1888,6 +1983,13 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     size_t lane_floats = 0;
     if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512) + 1024;
     const size_t o_wlane = carve(sizeof(float) * std::max<size_t>(1, lane_floats));
+    // lane-local 4x4x1 MLP of the specialised kernel: small nets whose whole image stays in registers
+    {
+        const int r4 = (p->fused_mlp && jit_possible && d->mlp_precision == MOLANN_MLP_F32 && d_feat <= LANE_MLP_MAX_WIDTH)
+                           ? mlp4_regs(p->dims, d->n_layers) : 0;
+        p->mlp4_regs = (r4 > 0 && r4 <= MLP4_MAX_REGS) ? r4 : 0;
+    }
+    const size_t o_wlane4 = carve(sizeof(float) * 64 * (size_t)std::max(4, (p->mlp4_regs + 3) & ~3));
     size_t mfma_bytes = 0;
     const bool bf16 = d->mlp_precision == MOLANN_MLP_BF16;
     const int kgran = bf16 ? 32 : 16;
@@ -1968,6 +2070,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_items_slot = (ItemDev*)(p->blob + o_items_slot);
     p->d_slots = (int*)(p->blob + o_slots);
     p->d_wlane = (float*)(p->blob + o_wlane);
+    p->d_wlane4 = (float*)(p->blob + o_wlane4);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
     p->d_wchain = p->blob + o_wchain;
@@ -2026,7 +2129,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         j.slots = slots; j.items = items_slot;
         // compact tile: only the 16-byte windows of a frame that hold a touched atom go to LDS, so more waves fit
         j.win = compact_windows(slots, d->n_inp);
-        jit_geometry(j, p->jit_geom, p->fused_mlp ? d_feat : cols_needed, cols_needed);
+        j.mlp_mode = (j.n_layers > 0 && p->mlp4_regs > 0) ? 1 : 0;
+        j.mlp4_regs = j.mlp_mode == 1 ? p->mlp4_regs : 0;
+        jit_geometry(j, p->jit_geom, j.mlp_mode == 1 ? 0 : (p->fused_mlp ? d_feat : cols_needed), cols_needed);
         if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
         p->spec = new (std::nothrow) JitSpecBox();
         if (p->spec) {
@@ -2035,33 +2140,26 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             p->n_grad_params = 0;
             for (int l = 0; l < j.n_layers; ++l) p->n_grad_params += p->dims[l + 1] * p->dims[l] + p->dims[l + 1];
         }
-        // Two waves per SIMD.  With the compact tile the LDS would hold 12 waves per CU and the kernel compiles to
-        // 166 registers without scratch, but measured (C3) the third wave slows the arithmetic more (52 -> 65 us with
-        // the HBM stream removed) than it hides of the stream: 73.4 us against 71.3.  C2 is the same either way (41.5 /
-        // 41.9).  MOLANN_DEBUG_JIT_WAVES=3 builds the three-wave variant (it falls back if that build needs scratch).
         int rc = -1;
         const bool frame_ok = p->jit_geom.ok && 3 * d->n_inp >= 4;
-        const long lds_waves = frame_ok ? (long)j.wpb * (163840 / ((long)j.wpb * j.lds_per_wave)) : 0;
-        int waves0 = 2;
-        if (const char* e = diag_env("MOLANN_DEBUG_JIT_WAVES")) waves0 = (atoi(e) >= 3 && lds_waves >= 12) ? 3 : 2;
-        for (int waves = waves0; frame_ok && waves >= 2 && !p->jit_fn; --waves) {
-            j.waves_per_eu = waves;
+        if (frame_ok) {
             std::vector<char> code;
             std::string log;
-            rc = jit_compile(jit_source(j), code, log);
+            // no SLP vectorisation: hipcc otherwise packs a fifth of this straight-line fp32 code into v_pk_* pairs, which
+            // buys ~1.2x on those operations at two waves per SIMD and pays for it with ~130 register moves per tile and 44
+            // more registers (C3: 166 -> 122 VGPRs, 74 -> 70 us; tools/ab_flags.sh)
+            rc = jit_compile(jit_source(j), code, log, "-fno-slp-vectorize");
             hipModule_t mod = nullptr;
             hipFunction_t fn = nullptr;
             if (rc != 0 || hipModuleLoadData(&mod, code.data()) != hipSuccess ||
                 hipModuleGetFunction(&fn, mod, "molann_lane_jit") != hipSuccess) {
                 if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
                 if (mod) (void)hipModuleUnload(mod);
-                break;
+            } else {
+                p->jit_mod = mod; p->jit_fn = fn; p->jit_nl = j.n_layers; p->jit_waves = 2;
+                p->jit_ncons = j.ncons; p->jit_nload = j.nload; p->jit_nslot = j.nslot; p->jit_bpc = j.bpc; p->jit_lds_block = j.lds_block;
+                snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %d+1 waves per block, %zu bytes", j.ncons, code.size());
             }
-            int scratch = 0;
-            (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
-            if (scratch > 0 && waves > 2) { (void)hipModuleUnload(mod); continue; }
-            p->jit_mod = mod; p->jit_fn = fn; p->jit_nl = j.n_layers; p->jit_waves = waves;
-            snprintf(p->jit_note, sizeof(p->jit_note), "jit: specialised kernel, %d waves/SIMD, %zu bytes", waves, code.size());
         }
         if (!p->jit_fn) snprintf(p->jit_note, sizeof(p->jit_note), "jit: unavailable (rc=%d), generic kernel", rc);
     }
@@ -2153,6 +2251,8 @@ int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* c
     a.bf16 = p->mlp_prec == MOLANN_MLP_BF16;
     if (p->fused_mlp)
         hipLaunchKernelGGL(pack_lane_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
+    if (p->mlp4_regs > 0)
+        hipLaunchKernelGGL(pack_lane4_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane4, a, p->act, p->mlp4_regs);
     // the MFMA copy serves molann_mlp_packed_f32 and the unfused forward
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(64, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wmfma, a);
     if (p->chain_fn) {
@@ -2397,7 +2497,12 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     if (d->n_layers > 0) j.dims.assign(d->layer_dims, d->layer_dims + d->n_layers + 1);
     molann_plan::LaneGeom g;
     j.win = compact_windows(j.slots, d->n_inp);
-    jit_geometry(j, g, col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
+    {
+        const int r4 = (d->n_layers > 0 && d->mlp_precision == MOLANN_MLP_F32 && col <= LANE_MLP_MAX_WIDTH) ? mlp4_regs(d->layer_dims, d->n_layers) : 0;
+        j.mlp_mode = (r4 > 0 && r4 <= MLP4_MAX_REGS) ? 1 : 0;
+        j.mlp4_regs = j.mlp_mode == 1 ? r4 : 0;
+    }
+    jit_geometry(j, g, j.mlp_mode == 1 ? 0 : col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
     if (!g.ok || 3 * d->n_inp < 4) return MOLANN_E_UNSUPPORTED;
     j.waves_per_eu = 2;
     std::string src = jit_source(j);
@@ -2420,7 +2525,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     if (do_compile & 1) {
         std::vector<char> code;
         std::string log;
-        const int rc = jit_compile(src, code, log);
+        const int rc = jit_compile(src, code, log, (do_compile & 2) ? nullptr : "-fno-slp-vectorize");
         if (rc != 0) {
             if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", log.c_str());
             return rc > 0 ? rc : MOLANN_E_UNSUPPORTED;
@@ -2429,12 +2534,14 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     return (int)src.size();
 }
 
-// diagnostic: read and clear the phase-stamp sums (8 x u64; [7] = number of waves that reported)
-int molann_debug_read_stamps(unsigned long long* out8) {
-    if (!out8) return MOLANN_E_NULL;
-    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// diagnostic: read and clear the phase-stamp sums (16 x u64; [0..5] consumer phases, [6] clock ratio, [7] = number of
+// consumer waves that reported, [8..10] loader: waiting for a free slot / issuing DMA / waiting for a tile to land,
+// [11] loader waves, [12] tiles issued)
+int molann_debug_read_stamps(unsigned long long* out16) {
+    if (!out16) return MOLANN_E_NULL;
+    unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(zero)));
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
     return MOLANN_OK;
 }

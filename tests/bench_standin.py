@@ -56,5 +56,8 @@ class CpuStandIn(object):
     def ms_between(self, a, b):
         return (b - a) * 1e3
 
+    def library(self):
+        return "none (oracle stand-in)"
+
     def kernels(self, model):
         return "oracle stand-in (tests only)"

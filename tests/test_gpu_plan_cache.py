@@ -154,10 +154,8 @@ def test_double_backward_is_refused_not_wrong(hip_device):
     for m in (model, torch.jit.script(model)):
         y = m(x)
         with pytest.raises(RuntimeError) as e:
-            (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
-            gx.pow(2).sum().backward()
-        msg = str(e.value)
-        assert "once_differentiable" in msg or "first-order" in msg, msg
+            torch.autograd.grad(y.sum(), x, create_graph=True)
+        assert "first-order" in str(e.value), str(e.value)
         (gx,) = torch.autograd.grad(m(x).sum(), x)       # first order still fine afterwards
         assert torch.isfinite(gx).all()
 

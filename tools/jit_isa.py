@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic (no GPU needed): the plan-specialised lane kernel of a workload as source and gfx950 ISA, with its
+resource usage and instruction mix.   python tools/jit_isa.py [C3] [outdir] [--bwd] [extra hipcc flags...]"""
+import collections, ctypes, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from molann_amd import _capi, workloads as wl
+from test_jit_host import _desc
+
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
+flags = [a for a in sys.argv[1:] if a.startswith("-") and a != "--bwd"]
+name = args[0] if args else "C3"
+out = args[1] if len(args) > 1 else "/tmp/jit_%s" % name
+os.makedirs(out, exist_ok=True)
+d, keep = _desc(wl.get_workload(name))
+buf = ctypes.create_string_buffer(1 << 21)
+rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 2 if "--bwd" in sys.argv else 0, buf, 1 << 21)
+assert rc > 0, rc
+src = os.path.join(out, "k.hip")
+open(src, "w").write(buf.value.decode())
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-I", os.path.join(ROOT, "molann_amd", "csrc"),
+       "-save-temps", "-Rpass-analysis=kernel-resource-usage", "-c", "k.hip", "-o", "k.o"] + flags
+p = subprocess.run(cmd, cwd=out, capture_output=True, text=True)
+for ln in p.stderr.splitlines():
+    if "remark" in ln and any(k in ln for k in ("VGPRs:", "AGPRs", "Spill", "Occupancy", "LDS Size", "SGPRs:", "ScratchSize")):
+        print(ln.split("remark:")[1].strip())
+if p.returncode != 0:
+    print(p.stderr[-3000:]); sys.exit(1)
+asm = [f for f in os.listdir(out) if f.endswith(".s")][0]
+mix = collections.Counter()
+for ln in open(os.path.join(out, asm)):
+    m = re.match(r"\s+([a-z_0-9]+)\s", ln)
+    if m and not m.group(1).startswith("."):
+        op = m.group(1)
+        key = ("mfma" if "mfma" in op else "trans" if re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", op) else "v_pk" if op.startswith("v_pk_") else
+               "valu_f64" if op.startswith("v_") and "f64" in op else "valu" if op.startswith("v_") else "salu" if op.startswith("s_") else
+               "lds" if op.startswith("ds_") else "vmem" if op.startswith(("global_", "buffer_", "flat_")) else "other")
+        mix[key] += 1
+print(out + "/" + asm, dict(mix))
