@@ -1018,61 +1018,6 @@ __global__ void pack_lane_kernel(float* __restrict__ dst, PackArgs p) {
     }
 }
 
-// ---- 4x4x1 image (specialised lane kernel, MLP_MODE 1) ---------------------------------------------------------
-// v_mfma_f32_4x4x1_16b_f32 keeps each of its 16 blocks inside 4 lanes: D_b[i][j] += A_b[i] * B_b[j], A_b[i] read
-// from lane 4b+i, B_b[j] from lane 4b+j, D_b[i][j] written to VGPR i of lane 4b+j (tools/micro/mfma4x4.hip).  With
-// lane = frame, B = the lane's own input k and A = four weights W[4g..4g+3][k] repeated over the blocks, every lane
-// gets units 4g..4g+3 of ITS OWN frame: a per-lane matrix-vector product with shared weights, no transposition
-// through LDS and no padding beyond the next multiple of four units.  One A operand per (layer, input k, unit group
-// g), k = K_l being the bias (its B operand is the constant 1):  operand r = base_l + k G_l + g, lane L =
-// Wf_l[4g + L%4][k].  The image is stored as quads of operands interleaved per lane ([r / 4][lane][r % 4]) so that a
-// consumer wave fetches four operands with one conflict-free ds_read_b128 from the block's LDS copy: the operands
-// are consumed in this order and live in registers only while they are used (a whole image would cost C3 122 VGPRs
-// and two of every four waves a SIMD can hold).
-//
-// Wf folds what is affine around the activation into the weights (exact in real arithmetic, rounded once here):
-// tanh and sigmoid are computed as r = 1 / (1 + 2^z') with z' = sigma z, and the next layer takes r itself:
-//   h = alpha + beta r   (tanh: alpha 1, beta -2, sigma 2 log2 e;  sigmoid: alpha 0, beta 1, sigma -log2 e)
-//   Wf_l = sigma_l beta_(l-1) W_l,   bf_l = sigma_l (b_l + alpha_(l-1) sum_k W_l[.,k]),
-// sigma_l = sigma for layers followed by the activation, 1 for the last; alpha_(-1) = 0, beta_(-1) = 1.  Other
-// activations: alpha 0, beta 1, sigma 1 (the kernel applies them as they are).  Two instructions per hidden unit
-// (v_exp, v_rcp + one add) instead of five.
-__host__ __device__ inline int mlp4_groups(int J) { return (J + 3) / 4; }
-inline int mlp4_regs(const int* dims, int nl) {
-    int r = 0;
-    for (int l = 0; l < nl; ++l) r += mlp4_groups(dims[l + 1]) * (dims[l] + 1);
-    return r;
-}
-constexpr int MLP4_MAX_REGS = 256;   // 64 quads: the ds_read offset field is 16 bits, and the image (<= 64 KiB) comes out of the ring's LDS
-
-__global__ void pack_lane4_kernel(float* __restrict__ dst, PackArgs p, int act, int total_regs) {
-    const double LOG2E = 1.4426950408889634;
-    const double alpha = act == 0 ? 1.0 : 0.0, beta = act == 0 ? -2.0 : 1.0;
-    const double sigma = act == 0 ? 2.0 * LOG2E : (act == 2 ? -LOG2E : 1.0);
-    const int padded = (total_regs + 3) & ~3;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < padded * 64; e += gridDim.x * blockDim.x) {
-        const int lane = (e >> 2) & 63;
-        int r = ((e >> 8) << 2) | (e & 3), l = 0;          // element e = [r / 4][lane][r % 4]
-        if (r >= total_regs) { dst[e] = 0.f; continue; }
-        while (l < p.n_layers && r >= mlp4_groups(p.dims[l + 1]) * (p.dims[l] + 1)) { r -= mlp4_groups(p.dims[l + 1]) * (p.dims[l] + 1); ++l; }
-        const int K = p.dims[l], J = p.dims[l + 1], G = mlp4_groups(J);
-        const int k = r / G, g = r - k * G;
-        const int u = 4 * g + (lane & 3);
-        const double sl = l + 1 < p.n_layers ? sigma : 1.0;
-        const double a_in = l > 0 ? alpha : 0.0, b_in = l > 0 ? beta : 1.0;
-        double v = 0.0;
-        if (u < J) {
-            if (k < K) v = sl * b_in * (double)p.W[l][(long)u * K + k];
-            else {
-                double sw = 0.0;
-                for (int kk = 0; kk < K; ++kk) sw += (double)p.W[l][(long)u * K + kk];
-                v = sl * ((double)p.b[l][u] + a_in * sw);
-            }
-        }
-        dst[e] = (float)v;
-    }
-}
-
 // mfma layout, layer l: Wp[Jp][Kp] (zero padded; fp32 or bf16) then bias[Jp] (fp32)
 __global__ void pack_mfma_kernel(void* __restrict__ dst_v, PackArgs p) {
     const int l = blockIdx.y;
@@ -1265,8 +1210,6 @@ struct molann_plan {
     double* d_ref64;   // the same in fp64 (covariance accumulation)
     ItemDev* d_items;
     float* d_wlane;    // fused layout
-    float* d_wlane4;   // 4x4x1 image of the specialised kernel's lane-local MLP (mlp4_regs registers x 64 lanes)
-    int mlp4_regs;     // 0: that kernel runs the 16x16x4 chained MLP from d_wlane
     void* d_wmfma;     // mfma layout
     float* d_work;     // two feature chunks [2][work_frames][d_feat] (ping-pong between gather and MLP kernels)
     long work_frames;
@@ -1458,8 +1401,7 @@ struct JitSpec { // what the specialised kernel is compiled for
     int waves_per_eu = 2;             // occupancy the backward kernel is compiled for (amdgpu_waves_per_eu)
     int nbuf = 1;
     // forward kernel: loader / consumer block around a ring of tile slots (molann_lane_jit.inc)
-    int mlp_mode = 0;                 // 1: lane-local 4x4x1 MLP (weights from the plan's d_wlane4 image)
-    int nload = 1, w_bytes = 0, mlp4_regs = 0;   // loaders per block; bytes / operands of the lane-local MLP's LDS image
+    int nload = 1;                    // loaders per block
     int ncons = 0, nslot = 0, depth = 0, ring_off = 0, tile_stride = 0, fb_off = 0, fb_bytes = 0, lds_block = 0, bpc = 0;
     std::vector<int> win;             // compact staging: first dword of each 16-byte window copied per frame
     std::vector<int> slots;           // slot -> atom
@@ -1498,7 +1440,7 @@ std::vector<int> compact_windows(const std::vector<int>& slot_atoms, int n_inp) 
 // the deepest ring, then the fewest blocks (= loader waves).
 void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fallback_cols) {
     const int tile = ceil_to(64 * 16 * (int)j.win.size(), 16);
-    const int fb = staging_rows > 0 ? ceil_to(staging_rows * FB_STRIDE * 4, 16) : 0; // none: the lane-local MLP stages nothing
+    const int fb = ceil_to(std::max(1, staging_rows) * FB_STRIDE * 4, 16);
     // One block per CU: 14 consumer waves + 2 loaders = four waves per SIMD (the kernel is built for <= 128 VGPRs).
     // Two loaders because a wave has at most 63 vector-memory operations in flight (vmcnt) = 63 KB of tiles, and
     // the loaded HBM latency (~4 us, tools/stamps.py) needs ~120 KB in flight per CU for 6 TB/s; the consumers beyond
@@ -1506,8 +1448,7 @@ void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fa
     j.bpc = 1;
     j.ncons = 14;
     j.nload = 2;
-    j.w_bytes = j.mlp_mode == 1 ? ((j.mlp4_regs + 3) / 4) * 1024 : 0;
-    const int header = 256 + j.w_bytes;
+    const int header = 256;
     long nslot = 0;
     auto fit = [&]() {
         nslot = std::min<long>(16, (163840 / j.bpc - header - (long)j.ncons * fb) / tile);
@@ -1598,7 +1539,7 @@ std::string jit_preamble(const JitSpec& j) {
     K("LDS_PER_WAVE", j.lds_per_wave); K("FBUF_OFF", j.fbuf_off);
     K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
     K("NCONS", j.ncons); K("NLOAD", j.nload); K("LDS_BLOCK", j.lds_block); K("NSLOT", j.nslot); K("DEPTH", j.depth); K("RING_OFF", j.ring_off); K("TILE_STRIDE", j.tile_stride);
-    K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes); K("MLP_MODE", j.mlp_mode); K("W_OFF", 256); K("W_BYTES", j.w_bytes);
+    K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes);
     {   // waves per SIMD the forward kernel must fit (its register budget): every wave of the (NCONS + 1)-wave blocks
         // a CU is to hold - the loader waves carry the consumers' allocation
         const int waves = (j.ncons + j.nload) * std::max(1, j.bpc);
@@ -1633,6 +1574,9 @@ std::string jit_preamble(const JitSpec& j) {
     s += (debug_env().ablate & 512) ? "constexpr bool NO_STORES = true;\n" : "constexpr bool NO_STORES = false;\n";
     // diagnostic (bit 2048): consumers hand every tile back as soon as it is in registers and compute nothing
     s += (debug_env().ablate & 2048) ? "constexpr bool NO_COMPUTE = true;\n" : "constexpr bool NO_COMPUTE = false;\n";
+    s += diag_env("MOLANN_DEBUG_TILE_CONTIG") ? "constexpr bool TILE_CONTIG = true;\n" : "constexpr bool TILE_CONTIG = false;\n"; // experiment
+    s += diag_env("MOLANN_DEBUG_ST_NT") ? "constexpr bool ST_NT = true;\n" : "constexpr bool ST_NT = false;\n"; // experiment: non-temporal output stores
+    { const char* e = diag_env("MOLANN_DEBUG_SLEEP"); K("SLEEP_N", e ? atoi(e) : 0); } // with NO_COMPUTE: idle ~8k cycles x N per tile
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }
@@ -1713,7 +1657,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         unsigned long long* stamps = nullptr;
         if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
         struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
-                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, (with_mlp && p->mlp4_regs > 0) ? p->d_wlane4 : p->d_wlane, n_frames, a.x_wide,
+                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
                                                                         a.out_vec4, stamps, p->d_ref};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
@@ -1983,13 +1927,6 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     size_t lane_floats = 0;
     if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512) + 1024;
     const size_t o_wlane = carve(sizeof(float) * std::max<size_t>(1, lane_floats));
-    // lane-local 4x4x1 MLP of the specialised kernel: small nets whose whole image stays in registers
-    {
-        const int r4 = (p->fused_mlp && jit_possible && d->mlp_precision == MOLANN_MLP_F32 && d_feat <= LANE_MLP_MAX_WIDTH)
-                           ? mlp4_regs(p->dims, d->n_layers) : 0;
-        p->mlp4_regs = (r4 > 0 && r4 <= MLP4_MAX_REGS) ? r4 : 0;
-    }
-    const size_t o_wlane4 = carve(sizeof(float) * 64 * (size_t)std::max(4, (p->mlp4_regs + 3) & ~3));
     size_t mfma_bytes = 0;
     const bool bf16 = d->mlp_precision == MOLANN_MLP_BF16;
     const int kgran = bf16 ? 32 : 16;
@@ -2070,7 +2007,6 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_items_slot = (ItemDev*)(p->blob + o_items_slot);
     p->d_slots = (int*)(p->blob + o_slots);
     p->d_wlane = (float*)(p->blob + o_wlane);
-    p->d_wlane4 = (float*)(p->blob + o_wlane4);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
     p->d_wchain = p->blob + o_wchain;
@@ -2129,9 +2065,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         j.slots = slots; j.items = items_slot;
         // compact tile: only the 16-byte windows of a frame that hold a touched atom go to LDS, so more waves fit
         j.win = compact_windows(slots, d->n_inp);
-        j.mlp_mode = (j.n_layers > 0 && p->mlp4_regs > 0) ? 1 : 0;
-        j.mlp4_regs = j.mlp_mode == 1 ? p->mlp4_regs : 0;
-        jit_geometry(j, p->jit_geom, j.mlp_mode == 1 ? 0 : (p->fused_mlp ? d_feat : cols_needed), cols_needed);
+        jit_geometry(j, p->jit_geom, p->fused_mlp ? d_feat : cols_needed, cols_needed);
         if (p->fused_mlp) j.dims.assign(p->dims, p->dims + d->n_layers + 1);
         p->spec = new (std::nothrow) JitSpecBox();
         if (p->spec) {
@@ -2251,8 +2185,6 @@ int molann_plan_update_mlp(molann_plan* p, const float* const* W, const float* c
     a.bf16 = p->mlp_prec == MOLANN_MLP_BF16;
     if (p->fused_mlp)
         hipLaunchKernelGGL(pack_lane_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane, a);
-    if (p->mlp4_regs > 0)
-        hipLaunchKernelGGL(pack_lane4_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, p->d_wlane4, a, p->act, p->mlp4_regs);
     // the MFMA copy serves molann_mlp_packed_f32 and the unfused forward
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(64, p->n_layers), dim3(256), 0, (hipStream_t)stream, p->d_wmfma, a);
     if (p->chain_fn) {
@@ -2497,12 +2429,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     if (d->n_layers > 0) j.dims.assign(d->layer_dims, d->layer_dims + d->n_layers + 1);
     molann_plan::LaneGeom g;
     j.win = compact_windows(j.slots, d->n_inp);
-    {
-        const int r4 = (d->n_layers > 0 && d->mlp_precision == MOLANN_MLP_F32 && col <= LANE_MLP_MAX_WIDTH) ? mlp4_regs(d->layer_dims, d->n_layers) : 0;
-        j.mlp_mode = (r4 > 0 && r4 <= MLP4_MAX_REGS) ? 1 : 0;
-        j.mlp4_regs = j.mlp_mode == 1 ? r4 : 0;
-    }
-    jit_geometry(j, g, j.mlp_mode == 1 ? 0 : col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
+    jit_geometry(j, g, col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
     if (!g.ok || 3 * d->n_inp < 4) return MOLANN_E_UNSUPPORTED;
     j.waves_per_eu = 2;
     std::string src = jit_source(j);

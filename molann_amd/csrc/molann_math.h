@@ -225,28 +225,50 @@ MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, float (&R)[9]) {
 
     // Newton from above; lambda_max <= s1+s2+s3 <= sqrt(3) |h|_F and <= e0 * s
     constexpr T sqrt3 = (T)1.7320508075688772;
-    T lam = e0 * s < sqrt3 ? e0 * s : sqrt3;
-    if (!(lam > (T)0)) lam = sqrt3;
-    bool done = false;
-    // bounded: every lane reaches the exit.  fp32: the residual's own rounding (~1e-7 / p'(lam)) keeps an
-    // ill-conditioned frame from ever meeting the step test, so the cap is what ends it there.
-    for (int it = 0; it < (F32 ? 12 : 48); ++it) {
-        if (!done) {
-            const T l2 = lam * lam;
-            const T p = (l2 + c2) * l2 + c1 * lam + c0;
-            const T dp = ((T)4 * l2 + (T)2 * c2) * lam + c1;
-            // Newton corrects itself: an fp32-accurate reciprocal is enough
-            const T step = p * (T)fast_rcp((float)dp);
-            const T nl = lam - step;
-            const bool finite = (step == step) && (tabs(nl) < (T)4);
-            if (finite) lam = nl;
-            if (!finite || !(tabs(step) > (F32 ? (T)1e-6f : (T)1e-14) * tabs(nl))) done = true;
-        }
+    T lam0 = e0 * s < sqrt3 ? e0 * s : sqrt3;
+    if (!(lam0 > (T)0)) lam0 = sqrt3;
+    // A frame that resembles the reference starts within ~1e-2 of the root (e0 is then tight) and Newton converges
+    // quadratically: NFIX unconditional steps - straight-line code, no exec-mask bookkeeping, nothing for the compiler
+    // to split into blocks - leave the last step below the tolerance.  Whatever has not converged by then (or went
+    // non-finite) takes the guarded loop below; a wave skips it when all its frames are done.
+    constexpr int NFIX = F32 ? 4 : 5;
+    const T tol = F32 ? (T)1e-6f : (T)1e-14;
+    T lam = lam0, step = (T)0;
+#pragma unroll
+    for (int it = 0; it < NFIX; ++it) {
+        const T l2 = lam * lam;
+        const T p = tfma(l2 + c2, l2, tfma(c1, lam, c0));
+        const T dp = tfma(tfma((T)4, l2, (T)2 * c2), lam, c1);
+        step = p * (T)fast_rcp((float)dp);   // Newton corrects itself: an fp32-accurate reciprocal is enough
+        lam = lam - step;
+    }
+    bool done = (step == step) && (tabs(lam) < (T)4) && !(tabs(step) > tol * tabs(lam));
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (__all(done)) break; // wave-uniform exit
+    if (!__all(done)) {
 #else
-        if (done) break;
+    if (!done) {
 #endif
+        if (!done && !((lam == lam) && lam > (T)0 && lam <= lam0)) lam = lam0;   // left the monotone path: start again
+        // bounded: every lane reaches the exit.  fp32: the residual's own rounding (~1e-7 / p'(lam)) keeps an
+        // ill-conditioned frame from ever meeting the step test, so the cap is what ends it there.
+#pragma unroll 1
+        for (int it = 0; it < (F32 ? 12 : 48); ++it) {
+            if (!done) {
+                const T l2 = lam * lam;
+                const T p = (l2 + c2) * l2 + c1 * lam + c0;
+                const T dp = ((T)4 * l2 + (T)2 * c2) * lam + c1;
+                const T st = p * (T)fast_rcp((float)dp);
+                const T nl = lam - st;
+                const bool finite = (st == st) && (tabs(nl) < (T)4);
+                if (finite) lam = nl;
+                if (!finite || !(tabs(st) > tol * tabs(nl))) done = true;
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__all(done)) break; // wave-uniform exit
+#else
+            if (done) break;
+#endif
+        }
     }
 
     // adj(K - lam I) = const * q q^T

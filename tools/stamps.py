@@ -29,6 +29,9 @@ if buf[11]:
     lt = max(1, buf[12])
     print("loader waves %d, cycles per tile issued: slot wait / poll %.0f, DMA issue %.0f, landing wait + publish %.0f"
           % (buf[11], buf[8] / lt, buf[9] / lt, buf[10] / lt))
+if buf[11]:
+    print("loaders published their last tile after %.1f us on average; the last consumer of the chip left after %.1f us"
+          % (buf[13] / buf[11] / 100.0, buf[15] / 100.0))
 rt, ck = buf[6] >> 32, (buf[6] & 0xffffffff) << 8
 if rt:
     print("shader clock held: %.0f MHz (sum over waves of s_memtime / s_memrealtime x 100 MHz); wave lifetime %.1f us" % (ck / rt * 100.0, rt / waves / 100.0))

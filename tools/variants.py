@@ -22,16 +22,18 @@ variants = {
     "Kabsch + features + MLP[6,32,8]": MolANN(PreprocessingANN(al, fl), create_sequential_nn([6, 32, 8])),
     "features + MLP[6,32,8] (no Kabsch)": MolANN(PreprocessingANN(None, fl), create_sequential_nn([6, 32, 8])),
 }
-xs = [w.make_frames(w.frames, device=dev, seed=i) for i in range(5)]
+NF = int(os.environ.get("FRAMES", w.frames))
+NB = 5 if NF <= (1 << 21) else 2
+xs = [w.make_frames(NF, device=dev, seed=i) for i in range(NB)]
 for name, m in variants.items():
     m = m.to(dev).requires_grad_(False)
     with torch.no_grad():
         for i in range(5):
-            m(xs[i % 5])
+            m(xs[i % NB])
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for i in range(40):
-            m(xs[i % 5])
+            m(xs[i % NB])
         b.record(); b.synchronize()
-    print("%-40s %.1f us / 1M frames   [%s]" % (name, a.elapsed_time(b) / 40 * 1e3, __import__('molann_amd.ann').ann.last_launch_info(m)[:28]))
+    print("%-40s %.1f us / 1M frames   [%s]" % (name, a.elapsed_time(b) / 40 * 1e3 * (1 << 20) / NF, __import__('molann_amd.ann').ann.last_launch_info(m)[:28]))
