@@ -17,6 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmolann_hip.so")
 # the diagnostics build (honours MOLANN_DEBUG_* / MOLANN_ELIDE_INVARIANT_ALIGNMENT): tools/ only, opt-in by name
 DIAG_LIB_PATH = os.path.join(_CSRC, "libmolann_hip_diag.so")
+SAN_LIB_PATH = os.path.join(_CSRC, "libmolann_hip_san.so")   # `make san`: host code under ASan + UBSan (CPU tests only)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "molann_hip.h")
 
 ABI_VERSION = 1
@@ -64,9 +65,11 @@ def lib():
     global _lib
     if _lib is None:
         path = DIAG_LIB_PATH if os.environ.get("MOLANN_DIAG_LIB") == "1" else LIB_PATH
+        if os.environ.get("MOLANN_SAN_LIB") == "1":   # tests/test_sanitized_host.py: the ASan + UBSan build of the host half
+            path = SAN_LIB_PATH
         if not os.path.exists(path):
             raise ImportError("%s not found: run `make -C %s%s` (or __graft_entry__.build())"
-                              % (path, _CSRC, " diag" if path == DIAG_LIB_PATH else ""))
+                              % (path, _CSRC, " diag" if path == DIAG_LIB_PATH else (" san" if path == SAN_LIB_PATH else "")))
         L = ctypes.CDLL(path)
         vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         sigs = {

@@ -1656,9 +1656,9 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         const size_t jlds = (size_t)debug_env().lds_pad;   // the kernel declares its block's LDS statically
         unsigned long long* stamps = nullptr;
         if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
-        struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int x_wide, out_vec4;
-                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.x_wide,
-                                                                        a.out_vec4, stamps, p->d_ref};
+        struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int out_vec4, pad_;
+                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.out_vec4, 0,
+                                                                        stamps, p->d_ref};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
         const int jblock = 64 * (p->jit_ncons + p->jit_nload);

@@ -51,12 +51,51 @@ class Feature(object):
                              'atom indices (1-based)': [self.get_atom_indices()]})
 
 
+def _tokenise(path):
+    """The feature file as a list of ``(line number, kind, text)`` with kind ``'header'`` (text = the name between
+    the brackets) or ``'entry'``; blank lines and ``#`` comment lines are dropped (`feature.py:147-194`)."""
+    tokens = []
+    with open(path, "r") as fh:
+        for lineno, raw in enumerate(fh, 1):
+            text = raw.strip()
+            if not text or text.startswith("#"):
+                continue
+            if text.startswith("["):
+                tokens.append((lineno, "header", text.strip("[]")))
+            else:
+                tokens.append((lineno, "entry", text))
+    return tokens
+
+
+def _section_entries(path, section_name):
+    """The entry lines of the FIRST ``[section_name]`` block: from its header to the next ``[End]`` (or the end of
+    the file).  Everything before that header is skipped whatever it is, as the reference does
+    (`feature.py:241-247`); a section that does not exist gives no entries.  One difference, on files the reference
+    cannot read either: another ``[Header]`` inside the open block - which the reference would hand to
+    ``str.split(',')`` and die of an unpacking ValueError - is rejected by name."""
+    tokens = _tokenise(path)
+    start = next((i for i, (_, kind, text) in enumerate(tokens) if kind == "header" and text == section_name), None)
+    if start is None:
+        return []
+    entries = []
+    for lineno, kind, text in tokens[start + 1:]:
+        if kind == "header":
+            if text == "End":
+                break
+            if text == section_name:      # the reference treats a repeated header of the open section as a no-op
+                continue
+            raise ValueError("%s:%d: section [%s] opened inside section [%s] (missing [End]?)"
+                             % (path, lineno, text, section_name))
+        entries.append((lineno, text))
+    return entries
+
+
 class FeatureFileReader(object):
     """Reads one ``[section] ... [End]`` block of a feature file (`feature.py:147-194, 224-265`).
 
     Each feature line is ``name, type, selector[, selector ...]``; the selectors are passed to
     ``universe.select_atoms`` and concatenated in order.  ``universe`` is an MDAnalysis Universe or a
-    :class:`molann_amd.atomgroup.Universe`.
+    :class:`molann_amd.atomgroup.Universe`.  A section that does not exist yields an empty list, as in the reference.
     """
 
     def __init__(self, feature_file, section_name, universe):
@@ -65,27 +104,21 @@ class FeatureFileReader(object):
         self.u = universe
         self.feature_list = []
 
+    def _feature_from_line(self, lineno, text):
+        fields = text.split(",")
+        if len(fields) < 2:
+            raise ValueError("%s:%d: expected 'name, type, selector[, selector ...]', got %r"
+                             % (self.feature_file, lineno, text))
+        name, ftype, selectors = fields[0].strip(), fields[1].strip(), fields[2:]
+        group = None
+        for selector in selectors:
+            part = self.u.select_atoms(selector)
+            group = part if group is None else group + part
+        return Feature(name, ftype, group)
+
     def read(self):
-        self.feature_list = []
-        in_section = False
-        with open(self.feature_file, "r") as cfg:
-            for line in cfg:
-                line = line.strip()
-                if not line or line.startswith("#"):
-                    continue
-                if line.startswith("["):
-                    if line.strip('[]') == self.section_name:
-                        in_section = True
-                        continue
-                    if in_section and line.strip('[]') == 'End':
-                        break
-                if in_section:
-                    name, ftype, *selectors = line.split(',')
-                    ag = None
-                    for sel in selectors:
-                        part = self.u.select_atoms(sel)
-                        ag = part if ag is None else ag + part
-                    self.feature_list.append(Feature(name.strip(), ftype.strip(), ag))
+        self.feature_list = [self._feature_from_line(lineno, text)
+                             for lineno, text in _section_entries(self.feature_file, self.section_name)]
         return self.feature_list
 
     def get_feature_list(self):
@@ -95,7 +128,5 @@ class FeatureFileReader(object):
         return len(self.feature_list)
 
     def get_feature_info(self):
-        df = pd.DataFrame()
-        for f in self.feature_list:
-            df = pd.concat([df, f.get_feature_info()], ignore_index=True)
-        return df
+        frames = [f.get_feature_info() for f in self.feature_list]
+        return pd.concat(frames, ignore_index=True) if frames else pd.DataFrame()

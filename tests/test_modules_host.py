@@ -169,6 +169,28 @@ def test_feature_file_reader(tmp_path):
     assert list(fl.get_feature_info()["type_id"]) == [2, 1, 0]
 
 
+def test_feature_file_reader_edge_cases(tmp_path):
+    f = tmp_path / "feat.txt"
+    f.write_text("[Broken]\nx1, bond, bynum 1 2\n"            # no [End]: skipped when another section is asked for
+                 "[Hist]\n\n# c\nb1, bond, bynum 2 5\n[Hist]\nb2, bond, bynum 5 6\n[End]\n"
+                 "[Hist]\nb3, bond, bynum 1 2\n[End]\n[Tail]\nb4, bond, bynum 7 9\n")
+    assert [x.get_name() for x in FeatureFileReader(str(f), "Hist", U).read()] == ["b1", "b2"]   # first block only
+    assert [x.get_name() for x in FeatureFileReader(str(f), "Tail", U).read()] == ["b4"]         # runs to the end of the file
+    assert FeatureFileReader(str(f), "Nope", U).read() == []
+    assert FeatureFileReader(str(f), "Nope", U).get_feature_info().empty
+    with pytest.raises(ValueError) as e:
+        FeatureFileReader(str(f), "Broken", U).read()
+    assert "[Hist]" in str(e.value) and "[Broken]" in str(e.value)
+    g = tmp_path / "bad.txt"
+    g.write_text("[S]\njust-a-name\n[End]\n")
+    with pytest.raises(ValueError):
+        FeatureFileReader(str(g), "S", U).read()
+    h = tmp_path / "types.txt"
+    h.write_text("[S]\nq, torsion, bynum 1 2 3 4\n[End]\n")
+    with pytest.raises(NotImplementedError):             # Feature's own validation (feature.py:82)
+        FeatureFileReader(str(h), "S", U).read()
+
+
 def test_workload_sizes_match_baseline_table():
     """algorithmic / dense bytes per frame."""
     want = {"C1": (84, 276), "C2": (84, 276), "C3": (140, 296), "C4": (None, 60032), "C5": (None, 60064)}
