@@ -706,6 +706,179 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
 }
 
 // =============================================================================================
+// frames_ring_kernel: features (+ alignment) of LARGE frames, loader / consumer waves around an LDS ring
+// =============================================================================================
+// frames_wave_kernel (above) lets every lane fetch its own atoms from global memory: a 128-byte line that holds
+// both an alignment atom and an item's atom, or atoms of items that sit in different 64-item rounds, is requested
+// several times, and what misses the L1 is fetched again from L2 / HBM (C5: 519 line fetches per frame for 392
+// distinct lines touched; the whole 60 000-byte frame is 469).  Here each frame is staged ONCE: the 16-byte windows
+// that hold a touched atom (the same greedy cover the specialised lane kernel uses, computed at plan creation) are
+// gathered by LDS-DMA into a compact image - lane l of instruction i copies window 64 i + l - by loader waves that
+// do nothing else, and consumer waves (one wave per frame, the arithmetic of frames_wave_kernel unchanged) read
+// their atoms from the image at the LDS positions the plan precomputed.  Hand-off as in molann_lane_jit.inc:
+// monotonic counters ready[s] / done[s] per slot, tiles taken in order from a block-wide counter; a consumer keeps
+// its slot for the whole frame (it computes from the image) and hands it back when the features are stored.
+// ND = LDS-DMA instructions per frame (a compile-time count: the loader's counted vmcnt waits need an immediate);
+// windows beyond the plan's count re-copy window 0 into the image's padding.
+struct RingArgs {
+    long n_frames;
+    int frame_bytes;   // 12 n_inp
+    int n_align, n_items, out_cols;
+    int n_win;         // windows staged per frame (<= 64 ND)
+    int n_slot, n_cons, n_load, depth;
+};
+constexpr int RING_HEADER = 256;
+
+template <int K>
+__device__ __forceinline__ void ring_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K < 64 ? K : 0) : "memory"); }
+template <int ND>
+__device__ __forceinline__ void ring_wait_frames(int k) { // at most k frames (ND operations each) of this wave in flight
+    switch (k) {
+    case 0: ring_wait_vmcnt<0>(); break;
+    case 1: ring_wait_vmcnt<ND>(); break;
+    case 2: ring_wait_vmcnt<2 * ND>(); break;
+    case 3: ring_wait_vmcnt<3 * ND>(); break;
+    case 4: ring_wait_vmcnt<4 * ND>(); break;
+    case 5: ring_wait_vmcnt<5 * ND>(); break;
+    default: ring_wait_vmcnt<6 * ND>(); break;
+    }
+}
+typedef __attribute__((address_space(3))) volatile int* ring_word_t;
+__device__ __forceinline__ int ring_peek(ring_word_t w) { return __builtin_amdgcn_readfirstlane(*w); }
+
+__device__ __forceinline__ V3 img_atom(const float* img, int pos) { return v3(img[pos], img[pos + 1], img[pos + 2]); }
+
+// (Measured and dropped: consumers that first copy their lanes' atoms to registers and hand the slot back at once -
+// 63 more VGPRs beside the fp64 covariance; C4 9.7 against 7.4 us per 1000 frames, C5 12.0 against 9.6.)
+template <int ND>
+__global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           const int* __restrict__ win_off, const int* __restrict__ align_pos,
+                                                           const float* __restrict__ ref, const double* __restrict__ ref64,
+                                                           const ItemDev* __restrict__ items_pos, RingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ring_word_t ready = (ring_word_t)(smem);        // [n_slot <= 16]
+    ring_word_t done = (ring_word_t)(smem + 64);
+    ring_word_t next = (ring_word_t)(smem + 128);
+    unsigned char* const ring = smem + RING_HEADER;
+    constexpr int IMG_BYTES = ND * 1024;
+
+    // frames of this block: f(n) = blockIdx.x + n * gridDim.x
+    const long f_step = (long)gridDim.x;
+    const int n_b = (long)blockIdx.x < a.n_frames ? (int)((a.n_frames - 1 - (long)blockIdx.x) / f_step) + 1 : 0;
+    if (threadIdx.x < 33) ((volatile int*)smem)[threadIdx.x] = 0;
+    __syncthreads();
+
+    if (wave >= a.n_cons) {
+        // =========================== loader ==========================================================
+        __builtin_amdgcn_s_setprio(3);
+        int goff[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { const int w = 64 * i + lane; goff[i] = win_off[w < a.n_win ? w : 0]; }
+        const int jl = wave - a.n_cons;
+        int n_issue = jl, n_pub = jl, inflight = 0;
+        while (n_pub < n_b) {
+            bool can_issue = n_issue < n_b && inflight <= a.depth;
+            if (can_issue) {
+                const int s = n_issue % a.n_slot, gen = n_issue / a.n_slot;
+                if (gen > 0 && ring_peek(done + s) < gen) {
+                    can_issue = false;
+                    if (inflight == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                }
+            }
+            if (can_issue) {
+                const long f = (long)blockIdx.x + (long)n_issue * f_step;
+                const unsigned char* gsrc = (const unsigned char*)x + f * (long)a.frame_bytes;
+                unsigned char* slot = ring + (size_t)(n_issue % a.n_slot) * IMG_BYTES;
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + goff[i]), (lptr_t)(slot + (size_t)i * 1024), 16, 0, 0);
+                n_issue += a.n_load;
+                ++inflight;
+            } else {
+                ring_wait_frames<ND>(inflight - 1);
+                ready[n_pub % a.n_slot] = n_pub / a.n_slot + 1;
+                n_pub += a.n_load;
+                --inflight;
+            }
+        }
+        return;
+    }
+
+    // =============================== consumers: one wave per frame ====================================
+    const auto refc = as_const(ref);
+    const bool has_align = a.n_align > 0;
+    for (;;) {
+        int n = 0;
+        if (lane == 0) n = __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n = __builtin_amdgcn_readfirstlane(n);
+        if (n >= n_b) break;
+        const long f = (long)blockIdx.x + (long)n * f_step;
+        const int s = n % a.n_slot, gen = n / a.n_slot;
+        while (ring_peek(ready + s) < gen + 1) __builtin_amdgcn_s_sleep(1);
+        const float* img = (const float*)(ring + (size_t)s * IMG_BYTES);
+
+        V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        if (has_align) c0 = img_atom(img, as_const(align_pos)[0]);
+        float R[9];
+        if (has_align) {
+            float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
+            double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            auto acc = [&](int i, V3 atom) {
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3 p = atom - c0;
+                sx += p.x; sy += p.y; sz += p.z;
+                g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
+                const double px = p.x, py = p.y, pz = p.z;
+                h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
+                h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
+                h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            };
+#pragma unroll 4
+            for (int i = lane; i < a.n_align; i += 64) acc(i, img_atom(img, align_pos[i]));
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            const int cb = 3 * a.n_align;
+            const auto r64c = as_const(ref64);
+            const double srx = r64c[cb], sry = r64c[cb + 1], srz = r64c[cb + 2], gref = r64c[cb + 3];
+            const float inv_a = refc[cb + 4], fa = refc[cb + 5];
+            dl = v3(sx * inv_a, sy * inv_a, sz * inv_a);
+            const double dx = dl.x, dy = dl.y, dz = dl.z;
+            h[0] = fma(-dx, srx, h[0]); h[1] = fma(-dx, sry, h[1]); h[2] = fma(-dx, srz, h[2]);
+            h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
+            h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
+            const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+        }
+        float* of = out + f * (long)a.out_cols;
+        auto item = [&](int type, int col, V3 p0, V3 p1, V3 p2, V3 p3) {
+            if (has_align) {
+                p0 = rotate((p0 - c0) - dl, R);
+                p1 = rotate((p1 - c0) - dl, R);
+                p2 = rotate((p2 - c0) - dl, R);
+                p3 = rotate((p3 - c0) - dl, R);
+            }
+            float v[3];
+            const int w = eval_item(type, p0, p1, p2, p3, v);
+            of[col] = v[0];
+            if (w > 1) of[col + 1] = v[1];
+            if (w > 2) of[col + 2] = v[2];
+        };
+#pragma unroll 2
+        for (int it = lane; it < a.n_items; it += 64) {
+            const int4 d0 = ((const int4*)items_pos)[2 * it];
+            const int2 d1 = ((const int2*)items_pos)[4 * it + 2];
+            item(d0.x, d0.y, img_atom(img, d0.z), img_atom(img, d0.w), img_atom(img, d1.x), img_atom(img, d1.y));
+        }
+        // every lane's reads of the image have returned before the slot goes back to the loaders
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        done[s] = gen + 1;
+    }
+}
+
+// =============================================================================================
 // frames_wave_bwd_kernel: dL/dx of frames_wave_kernel (features of large frames), one wave per frame
 // =============================================================================================
 // grad_out[f][d_feat] -> grad_x[f][n_inp][3].  The frame's gradient row is zeroed with coalesced stores, then
@@ -1250,6 +1423,12 @@ struct molann_plan {
     int chain_fb;              // 16-frame blocks per wave
     char chain_note[96];
     char mlp_info[96];         // name + geometry of the last MLP kernel launch
+    // large frames through frames_ring_kernel: per-frame window list, LDS positions of the alignment atoms and of the
+    // items' atoms inside the staged image; ring_nd = LDS-DMA instructions per frame (0: frames_wave_kernel serves the plan)
+    int* d_ring_win;
+    int* d_ring_align_pos;
+    ItemDev* d_ring_items;
+    int ring_nd, ring_nwin;
     int n_slots;
     bool regs_mode;
     int* d_slots;
@@ -1697,6 +1876,38 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
 #undef LAUNCH_LANE
         snprintf(p->last_info, sizeof(p->last_info), "frames_lane_kernel<%d,%s> grid=%d block=%d lds=%zu", w,
                  mode == 1 ? "align_out" : (regs ? "features_regs" : "features_lds"), grid, 64 * wpb, lds);
+    } else if (mode == 0 && p->ring_nd > 0 && getenv("MOLANN_NO_RING") == nullptr) {
+        // large frames, features: every frame staged once into an LDS ring by loader waves (frames_ring_kernel)
+        const int nd = p->ring_nd;
+        const int img = nd * 1024;
+        RingArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.n_frames = n_frames; ra.frame_bytes = 12 * p->n_inp; ra.n_align = p->n_align; ra.n_items = p->n_items;
+        ra.out_cols = a.out_cols; ra.n_win = p->ring_nwin;
+        ra.n_slot = std::min(16, (163840 - RING_HEADER) / img);
+        ra.n_load = ra.n_slot >= 6 ? 2 : 1;
+        // a consumer keeps its slot while it computes from the image: slots = consumers + what the loaders keep in flight
+        ra.n_cons = std::max(1, std::min(14, ra.n_slot - 2 * ra.n_load));
+        ra.depth = std::max(0, std::min(std::min(6, 63 / nd), (ra.n_slot - ra.n_cons) / ra.n_load - 1));
+        if (debug_env().wave_bpc > 0) ra.n_cons = std::max(1, std::min(ra.n_cons, debug_env().wave_bpc)); // MOLANN_WAVE_BPC: experiment with fewer consumers
+        const int block = 64 * (ra.n_cons + ra.n_load);
+        const size_t lds = (size_t)RING_HEADER + (size_t)ra.n_slot * img;
+        const int grid = (int)std::min<long>(n_frames, p->num_cus);
+#define LAUNCH_RING(N)                                                                                                    \
+    case N: {                                                                                                             \
+        static bool attr_##N = false;                                                                                     \
+        if (!attr_##N) { (void)hipFuncSetAttribute((const void*)frames_ring_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr_##N = true; } \
+        hipLaunchKernelGGL(frames_ring_kernel<N>, dim3(grid), dim3(block), lds, stream, x, out, p->d_ring_win, p->d_ring_align_pos, \
+                           p->d_ref, p->d_ref64, p->d_ring_items, ra);                                                     \
+    } break;
+        switch (nd) {
+            LAUNCH_RING(2) LAUNCH_RING(4) LAUNCH_RING(6) LAUNCH_RING(8) LAUNCH_RING(10) LAUNCH_RING(12) LAUNCH_RING(14) LAUNCH_RING(16)
+            LAUNCH_RING(18) LAUNCH_RING(20) LAUNCH_RING(22) LAUNCH_RING(24) LAUNCH_RING(26) LAUNCH_RING(28) LAUNCH_RING(30) LAUNCH_RING(32)
+        default: return MOLANN_E_UNSUPPORTED;
+        }
+#undef LAUNCH_RING
+        snprintf(p->last_info, sizeof(p->last_info), "frames_ring_kernel<ND=%d> (%d consumer + %d loader waves, ring of %d frames, %d windows) grid=%d block=%d lds=%zu",
+                 nd, ra.n_cons, ra.n_load, ra.n_slot, p->ring_nwin, grid, block, lds);
     } else {
         const int wpb = 4;
         // blocks per CU: all wave slots.  (The gather is HBM-latency bound and wants every wave it can get; the MLP
@@ -1923,6 +2134,40 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const size_t o_items = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
     const size_t o_items_slot = carve(sizeof(ItemDev) * std::max<size_t>(1, items.size()));
     const size_t o_slots = carve(sizeof(int) * std::max<size_t>(1, slots.size()));
+    // frames_ring_kernel tables (plans the lane kernels do not serve): windows, image positions
+    std::vector<int> ring_win, ring_align_pos;
+    std::vector<ItemDev> ring_items;
+    p->ring_nd = 0;
+    if (p->family == 1 && p->n_items > 0 && align_is_prefix) {
+        const std::vector<int> win = compact_windows(slots, d->n_inp);
+        static const int buckets[] = {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32};
+        int nd = 0;
+        for (int b : buckets)
+            if (nd == 0 && (long)b * 64 >= (long)win.size()) nd = b;
+        if (nd > 0) {
+            // dword position of the atom's x inside the image; its three dwords are contiguous there: either one
+            // window holds all of them (always so for the window clamped to the frame's end, which may overlap its
+            // predecessor), or the atom runs over the end of window k and window k + 1 starts right behind it
+            auto pos_of = [&](int atom) {
+                const int d0 = 3 * atom;
+                for (size_t k = 0; k < win.size(); ++k)
+                    if (d0 >= win[k] && d0 + 2 < win[k] + 4) return (int)(4 * k) + d0 - win[k];
+                for (size_t k = 0; k < win.size(); ++k)
+                    if (d0 >= win[k] && d0 < win[k] + 4) return (int)(4 * k) + d0 - win[k];
+                return 0;
+            };
+            for (int w : win) ring_win.push_back(4 * w);
+            for (int i = 0; i < d->n_align; ++i) ring_align_pos.push_back(pos_of(d->align_idx[i]));
+            ring_items = items;
+            for (auto& it : ring_items)
+                for (int i = 0; i < 4; ++i) it.idx[i] = pos_of(it.idx[i]);
+            p->ring_nd = nd;
+            p->ring_nwin = (int)win.size();
+        }
+    }
+    const size_t o_ring_win = carve(sizeof(int) * std::max<size_t>(1, ring_win.size()));
+    const size_t o_ring_apos = carve(sizeof(int) * std::max<size_t>(1, ring_align_pos.size()));
+    const size_t o_ring_items = carve(sizeof(ItemDev) * std::max<size_t>(1, ring_items.size()));
 
     size_t lane_floats = 0;
     if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512) + 1024;
@@ -1993,6 +2238,12 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         wf = std::max<long>(1024, std::min<long>(wf, 1l << 20)); // (narrow feature rows: few, large chunks - each costs ~6 host API calls)
         wf &= ~63l;
         wf = std::max<long>(512, (wf / 2) & ~63l); // per half
+        // Large frames: the feature rows are a few percent of the frame bytes, so letting them spill past the Infinity
+        // Cache costs little, while a chunk that small leaves the MLP kernel (one block per CU, 64 FB frames per block
+        // and step) a fraction of the chip: frames_ring_kernel holds every CU, the two kernels run one after the other,
+        // and C5's MLP took 3.7 us per 1000 frames in 24 576-frame chunks against 1.2 on its own.  Up to 256 MiB per half.
+        if (p->family == 1 && 12l * d->n_inp >= 32l * d_feat)
+            wf = std::max<long>(wf, std::min<long>(1l << 18, ((256l << 20) / ((long)d_feat * 4)) & ~63l));
         p->work_frames = wf;
         work_bytes = 2 * (size_t)wf * d_feat * 4;
     }
@@ -2006,6 +2257,9 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_items = (ItemDev*)(p->blob + o_items);
     p->d_items_slot = (ItemDev*)(p->blob + o_items_slot);
     p->d_slots = (int*)(p->blob + o_slots);
+    p->d_ring_win = (int*)(p->blob + o_ring_win);
+    p->d_ring_align_pos = (int*)(p->blob + o_ring_apos);
+    p->d_ring_items = (ItemDev*)(p->blob + o_ring_items);
     p->d_wlane = (float*)(p->blob + o_wlane);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
@@ -2042,6 +2296,12 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         e = hipMemcpy(p->d_items_slot, items_slot.data(), sizeof(ItemDev) * items.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !slots.empty())
         e = hipMemcpy(p->d_slots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->ring_nd > 0) {
+        e = hipMemcpy(p->d_ring_win, ring_win.data(), sizeof(int) * ring_win.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !ring_align_pos.empty())
+            e = hipMemcpy(p->d_ring_align_pos, ring_align_pos.data(), sizeof(int) * ring_align_pos.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_ring_items, ring_items.data(), sizeof(ItemDev) * ring_items.size(), hipMemcpyHostToDevice);
+    }
 
     if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
