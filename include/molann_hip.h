@@ -153,6 +153,27 @@ int molann_forward_f32(molann_plan* plan, const float* x, int64_t n_frames, cons
 int molann_mlp_packed_f32(const molann_plan* plan, const float* f, int64_t n_frames, float* out,
                           molann_stream_t stream);
 
+/* -- float64 ---------------------------------------------------------------------------------- */
+/* The reference's modules follow x.dtype: after `model.double()` the same forward runs in float64 (ann.py:187-197,
+ * 323-354).  These entry points are that mode: x, out, W[i], b[i], ref_x are DEVICE pointers to
+ * doubles (8-byte aligned), the plan is the same one (index tables do not depend on the dtype).  Everything is
+ * computed in double; nothing is packed: the Linear parameters are read from the caller's tensors at every call.
+ * Written for agreement with the reference's float64 run to rounding, not for speed (one wave per frame). */
+
+/* The `ref_x` buffer of a `.double()` AlignmentLayer: DEVICE [n_align*3] doubles, already centred. */
+int molann_plan_update_ref_f64(molann_plan* plan, const double* ref_x, molann_stream_t stream);
+/* AlignmentLayer.forward ann.py:157-199 in float64. */
+int molann_align_f64(const molann_plan* plan, const double* x, int64_t n_frames, double* out_xyz, molann_stream_t stream);
+/* PreprocessingANN.forward / FeatureLayer.forward ann.py:454-474, 553-565 in float64: out[N, feature_dim]. */
+int molann_features_f64(const molann_plan* plan, const double* x, int64_t n_frames, double* out, molann_stream_t stream);
+/* ann_layers ann.py:60-65 in float64 on features f[N, layer_dims[0]]: W, b HOST arrays of n_layers device pointers. */
+int molann_mlp_f64(const molann_plan* plan, const double* f, int64_t n_frames, const double* const* W, const double* const* b,
+                   double* out, molann_stream_t stream);
+/* MolANN.forward ann.py:620-624 in float64; features_work is a caller-owned DEVICE buffer of n_frames * feature_dim
+ * doubles (launch functions do not allocate). */
+int molann_forward_f64(const molann_plan* plan, const double* x, int64_t n_frames, const double* const* W, const double* const* b,
+                       double* features_work, double* out, molann_stream_t stream);
+
 /* -- backward (the reference relies on torch autograd, incl. through its SVD) -------- */
 
 /* Floats of the parameter-gradient buffer: for every Linear layer dW[J][K] (torch layout) then db[J]. */

@@ -88,6 +88,11 @@ def lib():
             "molann_forward_packed_f32": (i32, [vp, vp, i64, vp, vp]),
             "molann_forward_f32": (i32, [vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
             "molann_mlp_packed_f32": (i32, [vp, vp, i64, vp, vp]),
+            "molann_plan_update_ref_f64": (i32, [vp, vp, vp]),
+            "molann_align_f64": (i32, [vp, vp, i64, vp, vp]),
+            "molann_features_f64": (i32, [vp, vp, i64, vp, vp]),
+            "molann_mlp_f64": (i32, [vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
+            "molann_forward_f64": (i32, [vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp, vp]),
             "molann_plan_last_launch_info": (i32, [vp, ctypes.c_char_p, i32]),
             "molann_plan_grad_params_size": (i32, [vp]),
             "molann_plan_supports_backward": (i32, [vp]),
@@ -202,6 +207,31 @@ class Plan(object):
     def update_ref(self, ref_x):
         _check(lib().molann_plan_update_ref(self._handle, ctypes.c_void_p(ref_x.data_ptr()), self._stream()),
                "molann_plan_update_ref")
+
+    def update_ref_f64(self, ref_x):
+        _check(lib().molann_plan_update_ref_f64(self._handle, ctypes.c_void_p(ref_x.data_ptr()), self._stream()),
+               "molann_plan_update_ref_f64")
+
+    def align_f64(self, x, out):
+        return self._run("molann_align_f64", x, out, x.shape[0])
+
+    def features_f64(self, x, out):
+        return self._run("molann_features_f64", x, out, x.shape[0])
+
+    def forward_f64(self, x, weights, biases, work, out):
+        n = len(weights)
+        W = (ctypes.c_void_p * n)(*[w.data_ptr() for w in weights])
+        B = (ctypes.c_void_p * n)(*[b.data_ptr() for b in biases])
+        _check(lib().molann_forward_f64(self._handle, x.data_ptr(), x.shape[0], W, B, work.data_ptr(), out.data_ptr(),
+                                        self._stream()), "molann_forward_f64")
+        return out
+
+    def mlp_f64(self, f, weights, biases, out):
+        n = len(weights)
+        W = (ctypes.c_void_p * n)(*[w.data_ptr() for w in weights])
+        B = (ctypes.c_void_p * n)(*[b.data_ptr() for b in biases])
+        _check(lib().molann_mlp_f64(self._handle, f.data_ptr(), f.shape[0], W, B, out.data_ptr(), self._stream()), "molann_mlp_f64")
+        return out
 
     def update_mlp(self, weights, biases):
         n = len(weights)

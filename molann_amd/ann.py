@@ -9,8 +9,9 @@ in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
     MolANN(preprocessing_layer, ann_layers)                      ann.py:567-624
     create_sequential_nn(layer_dims, activation)                 ann.py:37-67
 
-There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 tensor that lives
-on a HIP device raises.  Gradients (w.r.t. x and the Linear parameters) come from hand-written backward
+There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 or float64 tensor that
+lives on a HIP device raises.  float64 (`model.double()(x.double())`, which the reference supports because its
+modules follow x.dtype) runs the `molann_*_f64` kernels: forward only.  Gradients (w.r.t. x and the Linear parameters) come from hand-written backward
 kernels: fused with the MLP for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32),
 features only on large frames (one wave per frame).  With an MLP outside the fused kernel (wider, ELU / GELU /
 Softplus, or any MLP on large frames) a forward under grad mode takes features and their gradient from the
@@ -123,12 +124,15 @@ def _wants_grad(x, grad_sources=()):
 
 
 def _device_input(x, grad_sources=(), backward_ok=False):
-    """The tensor the kernels read: float32, on a HIP device, contiguous.  Everything else raises."""
+    """The tensor the kernels read: float32 (or float64: forward only), on a HIP device, contiguous.  Everything else raises."""
     if not x.is_cuda:
         raise RuntimeError("molann_amd runs on the MI355X only: got a %s tensor (no CPU path; move x and the "
                            "module to a HIP device)" % x.device.type)
-    if x.dtype != torch.float32:
-        raise TypeError("molann_amd kernels are float32; got %s" % x.dtype)
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("molann_amd kernels are float32 / float64; got %s" % x.dtype)
+    if x.dtype == torch.float64 and _wants_grad(x, grad_sources):
+        raise NotImplementedError("the float64 kernels are forward only: call the float64 model under torch.no_grad() "
+                                  "(gradients come from the float32 kernels)")
     if not backward_ok and _wants_grad(x, grad_sources):
         raise NotImplementedError("no backward kernel for this module / plan yet: call it under "
                                   "torch.no_grad() (or freeze the parameters)")
@@ -190,11 +194,14 @@ class _PlanFunction(torch.autograd.Function):
 
 
 def _device_buffer(ref_x, x):
-    """The module's `ref_x` buffer must live where x lives (the reference's matmul, ann.py:187, raises
-    RuntimeError for mixed devices too)."""
+    """The module's `ref_x` buffer must live where x lives and have its dtype (the reference's matmul, ann.py:187,
+    raises RuntimeError for mixed devices and for mixed dtypes too)."""
     if ref_x.device != x.device:
         raise RuntimeError("Expected all tensors to be on the same device: ref_x is on %s, x on %s "
                            "(move the module with .to(x.device))" % (ref_x.device, x.device))
+    if ref_x.dtype != x.dtype:
+        raise RuntimeError("expected ref_x and x to have the same dtype, but got ref_x %s and x %s (call .double() / "
+                           ".float() on the module)" % (ref_x.dtype, x.dtype))
     return ref_x
 
 
@@ -265,8 +272,12 @@ class _PlanEntry(object):
 
     def sync_ref(self, ref_x):
         if self.ref_key is None or not self.ref_key.matches(ref_x):
-            r = ref_x if (ref_x.dtype == torch.float32 and ref_x.is_contiguous()) else ref_x.float().contiguous()
-            self.plan.update_ref(r)
+            if ref_x.dtype == torch.float64:      # the buffer of a `.double()` model: kept in double
+                r = ref_x.contiguous()
+                self.plan.update_ref_f64(r)
+            else:
+                r = ref_x if (ref_x.dtype == torch.float32 and ref_x.is_contiguous()) else ref_x.float().contiguous()
+                self.plan.update_ref(r)
             self.ref_key = _TensorKey(ref_x)
             self._ref_hold = r
 
@@ -359,7 +370,11 @@ class AlignmentLayer(_PlanOwner, torch.nn.Module):
                 return _PlanFunction.apply(x, entry, False).view(x.shape[0], self.input_atom_num, 3)
         out = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            self._entry(x).plan.align(x, out)
+            plan = self._entry(x).plan
+            if x.dtype == torch.float64:
+                plan.align_f64(x, out)
+            else:
+                plan.align(x, out)
         return out
 
 
@@ -447,7 +462,14 @@ def _run_features(feature_owner, x, align_layer, plan_owner=None):
 
     entry = _get_entry(owner, x, "features", build)
     if x.shape[0] == 0:
-        return torch.empty((0, entry.plan.feature_dim), dtype=torch.float32, device=x.device)
+        return torch.empty((0, entry.plan.feature_dim), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.float64:
+        with torch.cuda.device(x.device):
+            if align_layer is not None:
+                entry.sync_ref(_device_buffer(align_layer.ref_x, x))
+            out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float64, device=x.device)
+            entry.plan.features_f64(x, out)
+        return out
     with torch.cuda.device(x.device):
         if align_layer is not None:
             entry.sync_ref(_device_buffer(align_layer.ref_x, x))
@@ -602,7 +624,23 @@ class MolANN(_PlanOwner, torch.nn.Module):
         _check_input(x, fl.input_atom_num)
         x = _device_input(x, grad_sources=st["params"], backward_ok=True)
         if x.shape[0] == 0:
-            return torch.empty((0, st["out_dim"]), dtype=torch.float32, device=x.device)
+            return torch.empty((0, st["out_dim"]), dtype=x.dtype, device=x.device)
+        if x.dtype == torch.float64:
+            # `model.double()(x.double())`: the float64 kernels, the Linear parameters read as they are
+            lins = st["linears"]
+            w0 = lins[0].weight
+            if w0.device != x.device or w0.dtype != torch.float64:
+                raise RuntimeError("ann_layers must be float64 on %s for a float64 input (got %s on %s): call .double()"
+                                   % (x.device, w0.dtype, w0.device))
+            entry = st["entry"]()
+            with torch.cuda.device(x.device):
+                if al is not None:
+                    entry.sync_ref(_device_buffer(al.ref_x, x))
+                work = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float64, device=x.device)
+                out = torch.empty((x.shape[0], st["out_dim"]), dtype=torch.float64, device=x.device)
+                entry.plan.forward_f64(x, [lin.weight.detach().contiguous() for lin in lins],
+                                       [lin.bias.detach().contiguous() for lin in lins], work, out)
+            return out
         if _wants_grad(x, st["params"]):
             w0 = st["linears"][0].weight
             if w0.device != x.device or w0.dtype != torch.float32:

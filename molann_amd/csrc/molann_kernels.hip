@@ -879,6 +879,109 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
 }
 
 // =============================================================================================
+// float64 path: the same forward for `model.double()(x.double())` (the reference follows x.dtype, ann.py:187-197)
+// =============================================================================================
+// One wave per frame, any frame size, everything in double (covariance, quaternion solve, rotation, features, MLP):
+// written for agreement with the reference's float64 run to rounding (tests: 1e-10), not for speed - float64 is the
+// reference's validation mode, float32 its production mode.  mode 0: features -> out[f][out_cols]; mode 1: aligned
+// coordinates -> out[f][n_inp][3].  The alignment reference comes from the plan's float64 copy (d_ref64: the centred
+// coordinates, their sums and the two constants, see pack_ref_kernel / molann_plan_update_ref_f64).
+struct F64Args {
+    long n_frames;
+    int n_inp, n_align, n_items, out_cols, mode;
+};
+__device__ __forceinline__ V3d load_atom_f64(const double* __restrict__ xf, int k) { return v3d(xf[3 * k], xf[3 * k + 1], xf[3 * k + 2]); }
+
+__global__ __launch_bounds__(256) void frames_f64_kernel(const double* __restrict__ x, double* __restrict__ out,
+                                                         const int* __restrict__ align_idx, const double* __restrict__ ref64,
+                                                         const ItemDev* __restrict__ items, F64Args a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const long frame_dw = 3l * a.n_inp;
+    for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
+        const double* xf = x + f * frame_dw;
+        double R[9] = {1., 0., 0., 0., 1., 0., 0., 0., 1.};
+        V3d c = v3d(0., 0., 0.);
+        if (a.n_align > 0) {
+            // centroid of the alignment atoms (ann.py:181), then H = sum (p - c) ref^T (ann.py:183-187), both as wave sums
+            double sx = 0., sy = 0., sz = 0.;
+            for (int i = lane; i < a.n_align; i += 64) { const V3d p = load_atom_f64(xf, align_idx[i]); sx += p.x; sy += p.y; sz += p.z; }
+            const double inv_a = 1.0 / (double)a.n_align;
+            c = v3d(wave_sum(sx) * inv_a, wave_sum(sy) * inv_a, wave_sum(sz) * inv_a);
+            double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, g = 0.;
+            for (int i = lane; i < a.n_align; i += 64) {
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3d p = load_atom_f64(xf, align_idx[i]) - c;
+                g = fma(p.x, p.x, fma(p.y, p.y, fma(p.z, p.z, g)));
+                h[0] = fma(p.x, rx, h[0]); h[1] = fma(p.x, ry, h[1]); h[2] = fma(p.x, rz, h[2]);
+                h[3] = fma(p.y, rx, h[3]); h[4] = fma(p.y, ry, h[4]); h[5] = fma(p.y, rz, h[5]);
+                h[6] = fma(p.z, rx, h[6]); h[7] = fma(p.z, ry, h[7]); h[8] = fma(p.z, rz, h[8]);
+            }
+            g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            const double gref = ref64[3 * a.n_align + 3];
+            kabsch_rotation_t<double, double>(h, 0.5 * (g + gref) * 1.0001, R);
+        }
+        if (a.mode == 1) {
+            double* of = out + f * frame_dw;
+            for (int k = lane; k < a.n_inp; k += 64) {
+                const V3d y = rotate(load_atom_f64(xf, k) - c, R);
+                of[3 * k] = y.x; of[3 * k + 1] = y.y; of[3 * k + 2] = y.z;
+            }
+            continue;
+        }
+        double* of = out + f * (long)a.out_cols;
+        for (int it = lane; it < a.n_items; it += 64) {
+            const ItemDev d = items[it];
+            V3d p0 = load_atom_f64(xf, d.idx[0]), p1 = load_atom_f64(xf, d.idx[1]), p2 = load_atom_f64(xf, d.idx[2]), p3 = load_atom_f64(xf, d.idx[3]);
+            if (a.n_align > 0) { p0 = rotate(p0 - c, R); p1 = rotate(p1 - c, R); p2 = rotate(p2 - c, R); p3 = rotate(p3 - c, R); }
+            double v[3];
+            const int w = eval_item_f64(d.type, p0, p1, p2, p3, v);
+            of[d.col] = v[0];
+            if (w > 1) of[d.col + 1] = v[1];
+            if (w > 2) of[d.col + 2] = v[2];
+        }
+    }
+}
+
+// ann_layers in double: one wave per frame, the activations ping-pong between two LDS rows, lane j computes units j,
+// j + 64, ... of a layer as one fma chain over the inputs (weights read from the caller's tensors as they are: the
+// torch.nn.Linear layout W[J][K], b[J]).
+struct F64Mlp {
+    int n_layers, act, max_w;
+    int dims[MOLANN_MAX_LAYERS + 1];
+    const double* W[MOLANN_MAX_LAYERS];
+    const double* b[MOLANN_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void mlp_f64_kernel(const double* __restrict__ in, double* __restrict__ out, long n_frames, F64Mlp m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    double* buf0 = (double*)smem + (size_t)wave * 2 * m.max_w;
+    double* buf1 = buf0 + m.max_w;
+    for (long f = (long)blockIdx.x * wpb + wave; f < n_frames; f += (long)gridDim.x * wpb) {
+        for (int k = lane; k < m.dims[0]; k += 64) buf0[k] = in[f * (long)m.dims[0] + k];
+        double* cur = buf0;
+        double* nxt = buf1;
+        for (int l = 0; l < m.n_layers; ++l) {
+            const int K = m.dims[l], J = m.dims[l + 1];
+            const bool last = l + 1 == m.n_layers;
+            for (int j = lane; j < J; j += 64) {
+                const double* w = m.W[l] + (long)j * K;
+                double acc = m.b[l][j];
+                for (int k = 0; k < K; ++k) acc = fma(w[k], cur[k], acc);
+                if (last) out[f * (long)J + j] = acc;
+                else nxt[j] = apply_activation_f64(m.act, acc);
+            }
+            double* t = cur; cur = nxt; nxt = t;
+        }
+    }
+}
+
+// =============================================================================================
 // frames_wave_bwd_kernel: dL/dx of frames_wave_kernel (features of large frames), one wave per frame
 // =============================================================================================
 // grad_out[f][d_feat] -> grad_x[f][n_inp][3].  The frame's gradient row is zeroed with coalesced stores, then
@@ -1301,14 +1404,15 @@ __global__ void pack_chain_kernel(unsigned char* __restrict__ dst, ChainPackArgs
 }
 
 // ref_x (device, centred) -> plan copy + the constants the kernels need after it
-__global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ dst64, const float* __restrict__ ref,
+template <typename S> // S = float: the module's buffer as the reference builds it; double: a `.double()` model's buffer
+__global__ void pack_ref_kernel(float* __restrict__ dst, double* __restrict__ dst64, const S* __restrict__ ref,
                                 int n_align) {
     if (blockIdx.x != 0) return;
     __shared__ double red[4][256];
     double s[4] = {0., 0., 0., 0.};
     for (int i = threadIdx.x; i < n_align; i += blockDim.x) {
-        const float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
-        dst[3 * i] = rx; dst[3 * i + 1] = ry; dst[3 * i + 2] = rz;
+        const S rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+        dst[3 * i] = (float)rx; dst[3 * i + 1] = (float)ry; dst[3 * i + 2] = (float)rz;
         dst64[3 * i] = rx; dst64[3 * i + 1] = ry; dst64[3 * i + 2] = rz;
         s[0] += rx; s[1] += ry; s[2] += rz;
         s[3] += (double)rx * rx + (double)ry * ry + (double)rz * rz;
@@ -2425,7 +2529,14 @@ int molann_plan_last_launch_info(const molann_plan* p, char* buf, int cap) {
 int molann_plan_update_ref(molann_plan* p, const float* ref_x, molann_stream_t stream) {
     if (!p || !ref_x) return MOLANN_E_NULL;
     if (p->n_align <= 0) return MOLANN_E_STAGE;
-    hipLaunchKernelGGL(pack_ref_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p->d_ref, p->d_ref64, ref_x, p->n_align);
+    hipLaunchKernelGGL(pack_ref_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, p->d_ref, p->d_ref64, ref_x, p->n_align);
+    return (int)hipGetLastError();
+}
+
+int molann_plan_update_ref_f64(molann_plan* p, const double* ref_x, molann_stream_t stream) {
+    if (!p || !ref_x) return MOLANN_E_NULL;
+    if (p->n_align <= 0) return MOLANN_E_STAGE;
+    hipLaunchKernelGGL(pack_ref_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, p->d_ref, p->d_ref64, ref_x, p->n_align);
     return (int)hipGetLastError();
 }
 
@@ -2558,6 +2669,75 @@ int molann_forward_f32(molann_plan* p, const float* x, int64_t n, const float* c
     const int e = molann_plan_update_mlp(p, W, b, stream);
     if (e != MOLANN_OK) return e;
     return molann_forward_packed_f32(p, x, n, out, stream);
+}
+
+
+// ---- float64 entry points (the reference's modules follow x.dtype) -------------------------------------------------
+static int check_io_f64(const void* x, const void* out, int64_t n) {
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !out) return MOLANN_E_NULL;
+    if ((((uintptr_t)x) & 7) || (((uintptr_t)out) & 7)) return MOLANN_E_ALIGNMENT;
+    return MOLANN_OK;
+}
+
+static int launch_f64(const molann_plan* p, const double* x, int64_t n, double* out, int mode, hipStream_t stream) {
+    F64Args a;
+    a.n_frames = n; a.n_inp = p->n_inp; a.n_align = p->n_align; a.n_items = p->n_items; a.out_cols = p->d_feat; a.mode = mode;
+    const int grid = grid_for(p, n, 4, 8);
+    hipLaunchKernelGGL(frames_f64_kernel, dim3(grid), dim3(256), 0, stream, x, out, p->d_align_idx, p->d_ref64, p->d_items, a);
+    return (int)hipGetLastError();
+}
+
+int molann_align_f64(const molann_plan* p, const double* x, int64_t n, double* out_xyz, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (p->n_align <= 0) return MOLANN_E_STAGE;
+    const int c = check_io_f64(x, out_xyz, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    snprintf(const_cast<molann_plan*>(p)->last_info, sizeof(p->last_info), "frames_f64_kernel (aligned coordinates)");
+    return launch_f64(p, x, n, out_xyz, 1, (hipStream_t)stream);
+}
+
+int molann_features_f64(const molann_plan* p, const double* x, int64_t n, double* out, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (p->n_items <= 0) return MOLANN_E_STAGE;
+    const int c = check_io_f64(x, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    snprintf(const_cast<molann_plan*>(p)->last_info, sizeof(p->last_info), "frames_f64_kernel (features)");
+    return launch_f64(p, x, n, out, 0, (hipStream_t)stream);
+}
+
+int molann_mlp_f64(const molann_plan* p, const double* f, int64_t n, const double* const* W, const double* const* b, double* out,
+                   molann_stream_t stream) {
+    if (!p || !W || !b) return MOLANN_E_NULL;
+    if (p->n_layers <= 0) return MOLANN_E_STAGE;
+    const int c = check_io_f64(f, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    F64Mlp m;
+    memset(&m, 0, sizeof(m));
+    m.n_layers = p->n_layers; m.act = p->act;
+    for (int i = 0; i <= p->n_layers; ++i) { m.dims[i] = p->dims[i]; m.max_w = std::max(m.max_w, p->dims[i]); }
+    for (int l = 0; l < p->n_layers; ++l) {
+        if (!W[l] || !b[l]) return MOLANN_E_NULL;
+        m.W[l] = W[l]; m.b[l] = b[l];
+    }
+    const size_t lds = (size_t)4 * 2 * m.max_w * sizeof(double);
+    if (lds > 65536) return MOLANN_E_UNSUPPORTED;
+    const int grid = grid_for(p, n, 4, 8);
+    hipLaunchKernelGGL(mlp_f64_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, f, out, (long)n, m);
+    return (int)hipGetLastError();
+}
+
+int molann_forward_f64(const molann_plan* p, const double* x, int64_t n, const double* const* W, const double* const* b,
+                       double* features_work, double* out, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (p->n_layers <= 0 || p->n_items <= 0) return MOLANN_E_STAGE;
+    if (n > 0 && !features_work) return MOLANN_E_NULL;
+    int e = molann_features_f64(p, x, n, features_work, stream);
+    if (e != MOLANN_OK || n == 0) return e;
+    e = molann_mlp_f64(p, features_work, n, W, b, out, stream);
+    snprintf(const_cast<molann_plan*>(p)->last_info, sizeof(p->last_info), "frames_f64_kernel (features) + mlp_f64_kernel");
+    return e;
 }
 
 int molann_plan_grad_params_size(const molann_plan* p) { return p ? p->n_grad_params : MOLANN_E_NULL; }

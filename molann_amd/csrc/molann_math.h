@@ -182,8 +182,8 @@ MOLANN_HD double tabs(double a) { return fabs(a); }
 // algorithm at the reference's own precision (its SVD runs in fp32) for plans whose items are all invariant
 // under rigid motion (bond / angle / dihedral): their outputs do not depend on how accurate R is, only on R
 // being a proper rotation, which the normalised quaternion guarantees in either precision.
-template <typename T>
-MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, float (&R)[9]) {
+template <typename T, typename RT = float>
+MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, RT (&R)[9]) {
     constexpr bool F32 = sizeof(T) == 4;
     const T tiny = F32 ? (T)1e-30f : (T)1e-30, huge = F32 ? (T)1e30f : (T)1e30;
     T fro2 = (T)0;
@@ -191,7 +191,7 @@ MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, float (&R)[9]) {
     for (int i = 0; i < 9; ++i) fro2 = tfma(H[i], H[i], fro2);
     if (!(fro2 > tiny) || !(fro2 < huge)) { // zero / non-finite covariance: no rotation
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? (RT)1 : (RT)0;
         return;
     }
     // scale so that |h|_F ~= 1: the rotation does not depend on the scale, so an fp32 rsqrt is enough
@@ -296,25 +296,26 @@ MOLANN_HD void kabsch_rotation_t(const T (&H)[9], T e0, float (&R)[9]) {
     const T n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
     if (!(n2 > tiny) || !(n2 < huge)) { // K - lam I numerically zero: degenerate input
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? (RT)1 : (RT)0;
         return;
     }
     // 1/n2: fp32 reciprocal seed + one Newton step in fp64 (relative error ~1e-14)
     T inv = (T)fast_rcp((float)n2);
     inv = inv * ((T)2 - n2 * inv);
+    if (sizeof(RT) == 8) inv = inv * ((T)2 - n2 * inv);   // rotation wanted in double: one more step (1e-14 -> rounding)
     const T ww = q0 * q0 * inv, xx = q1 * q1 * inv, yy = q2 * q2 * inv, zz = q3 * q3 * inv;
     const T wx = q0 * q1 * inv, wy = q0 * q2 * inv, wz = q0 * q3 * inv;
     const T xy = q1 * q2 * inv, xz = q1 * q3 * inv, yz = q2 * q3 * inv;
     // Q (column convention, maps frame -> reference); R = Q^T for row vectors
-    R[0] = (float)(ww + xx - yy - zz);
-    R[1] = (float)((T)2 * (xy + wz));
-    R[2] = (float)((T)2 * (xz - wy));
-    R[3] = (float)((T)2 * (xy - wz));
-    R[4] = (float)(ww - xx + yy - zz);
-    R[5] = (float)((T)2 * (yz + wx));
-    R[6] = (float)((T)2 * (xz + wy));
-    R[7] = (float)((T)2 * (yz - wx));
-    R[8] = (float)(ww - xx - yy + zz);
+    R[0] = (RT)(ww + xx - yy - zz);
+    R[1] = (RT)((T)2 * (xy + wz));
+    R[2] = (RT)((T)2 * (xz - wy));
+    R[3] = (RT)((T)2 * (xy - wz));
+    R[4] = (RT)(ww - xx + yy - zz);
+    R[5] = (RT)((T)2 * (yz + wx));
+    R[6] = (RT)((T)2 * (xz + wy));
+    R[7] = (RT)((T)2 * (yz - wx));
+    R[8] = (RT)(ww - xx - yy + zz);
 }
 
 MOLANN_HD void kabsch_rotation(const double (&H)[9], double e0, float (&R)[9]) { kabsch_rotation_t<double>(H, e0, R); }
@@ -324,6 +325,70 @@ MOLANN_HD void kabsch_rotation_f32(const float (&H)[9], float e0, float (&R)[9])
 MOLANN_HD V3 rotate(V3 p, const float (&R)[9]) {
     return v3(fmaf(p.z, R[6], fmaf(p.y, R[3], p.x * R[0])), fmaf(p.z, R[7], fmaf(p.y, R[4], p.x * R[1])),
               fmaf(p.z, R[8], fmaf(p.y, R[5], p.x * R[2])));
+}
+
+// =================================================================================================
+// float64 instantiation of the forward (the reference follows x.dtype: `model.double()(x.double())`, ann.py:187-197,
+// 323-354).  Plain double arithmetic with libm - no fast approximations: the bar is 1e-10 against the reference's
+// own float64 run.
+// =================================================================================================
+struct V3d {
+    double x, y, z;
+};
+MOLANN_HD V3d v3d(double x, double y, double z) { V3d r; r.x = x; r.y = y; r.z = z; return r; }
+MOLANN_HD V3d operator-(V3d a, V3d b) { return v3d(a.x - b.x, a.y - b.y, a.z - b.z); }
+MOLANN_HD double dot(V3d a, V3d b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+MOLANN_HD V3d cross(V3d a, V3d b) {
+    return v3d(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+}
+MOLANN_HD V3d rotate(V3d p, const double (&R)[9]) {
+    return v3d(fma(p.z, R[6], fma(p.y, R[3], p.x * R[0])), fma(p.z, R[7], fma(p.y, R[4], p.x * R[1])),
+               fma(p.z, R[8], fma(p.y, R[5], p.x * R[2])));
+}
+// eval_item in double (same item types, same column order)
+MOLANN_HD int eval_item_f64(int type, V3d a0, V3d a1, V3d a2, V3d a3, double (&out)[3]) {
+    switch (type) {
+    case IT_ANGLE_COS:
+    case IT_ANGLE_VAL: {
+        const V3d r21 = a0 - a1, r23 = a2 - a1;
+        const double c = dot(r21, r23) / (sqrt(dot(r21, r21)) * sqrt(dot(r23, r23)));   // ann.py:324-328, no clamp
+        out[0] = type == IT_ANGLE_VAL ? acos(c) : c;
+        return 1;
+    }
+    case IT_BOND: {
+        const V3d r = a1 - a0;
+        out[0] = sqrt(dot(r, r));
+        return 1;
+    }
+    case IT_DIHEDRAL_CS:
+    case IT_DIHEDRAL_VAL: {
+        const V3d r12 = a1 - a0, r23 = a2 - a1, r34 = a3 - a2;
+        const V3d n1 = cross(r12, r23), n2 = cross(r23, r34);
+        const double c = dot(n1, n2), sn = dot(n1, r34) * sqrt(dot(r23, r23));
+        if (type == IT_DIHEDRAL_VAL) { out[0] = atan2(sn, c); return 1; }
+        const double radius = sqrt(fma(c, c, sn * sn));                              // ann.py:346
+        out[0] = c / radius;
+        out[1] = sn / radius;
+        return 2;
+    }
+    default:
+        out[0] = a0.x; out[1] = a0.y; out[2] = a0.z;
+        return 3;
+    }
+}
+MOLANN_HD double apply_activation_f64(int act, double v) {
+    switch (act) {
+    case 0: return tanh(v);
+    case 1: return v > 0.0 ? v : (v != v ? v : 0.0);
+    case 2: return 1.0 / (1.0 + exp(-v));
+    case 3: return v;
+    case 4: return v > 0.0 ? v : expm1(v);
+    case 5: return v / (1.0 + exp(-v));
+    case 6: return v > 20.0 ? v : log1p(exp(v));
+    case 7: return v > 0.0 ? v : 0.01 * v;
+    case 8: return 0.5 * v * (1.0 + erf(v * 0.70710678118654752));
+    default: return v;
+    }
 }
 
 // =================================================================================================

@@ -217,12 +217,17 @@ at::Tensor device_f32(const at::Tensor& t, const at::Tensor& like, const char* n
 void sync_live(Entry& e, const at::Tensor& x, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
                const std::vector<at::Tensor>& biases, hipStream_t stream) {
     if (e.n_align > 0) {
-        const at::Tensor r = device_f32(ref_x.detach(), x, "ref_x");
+        TORCH_CHECK(ref_x.scalar_type() == x.scalar_type(), "molann::run: expected ref_x and x to have the same dtype, but got ",
+                    ref_x.scalar_type(), " and ", x.scalar_type());
+        TORCH_CHECK(ref_x.device() == x.device(), "molann::run: ref_x is on ", ref_x.device(), " but x is on ", x.device());
         if (e.dirty || always_repack() || !e.ref_key.matches(ref_x)) {
-            check(molann_plan_update_ref(e.plan, r.data_ptr<float>(), stream), "molann_plan_update_ref");
+            const at::Tensor r = ref_x.detach().contiguous();
+            if (r.scalar_type() == at::kDouble) check(molann_plan_update_ref_f64(e.plan, r.data_ptr<double>(), stream), "molann_plan_update_ref_f64");
+            else check(molann_plan_update_ref(e.plan, r.data_ptr<float>(), stream), "molann_plan_update_ref");
             e.ref_key = key_of(ref_x);
         }
     }
+    if (x.scalar_type() == at::kDouble) { e.dirty = false; return; }   // float64: the Linear parameters are read as they are
     if (e.kind == KIND_FORWARD) {
         TORCH_CHECK((int)weights.size() == e.n_layers && (int)biases.size() == e.n_layers,
                     "molann::run: expected ", e.n_layers, " weight and bias tensors");
@@ -250,7 +255,8 @@ void check_x(const at::Tensor& x, const std::vector<int64_t>& desc) {
     TORCH_CHECK(desc.size() >= DESC_HEAD, "molann::run: bad descriptor");
     TORCH_CHECK(x.dim() == 3 && x.size(1) == desc[2] && x.size(2) == 3, "Input should be a 3d torch tensor, with sizes [*, ",
                 desc[2], ", 3]. Actual sizes: ", x.sizes());
-    TORCH_CHECK(x.scalar_type() == at::kFloat, "molann_amd kernels are float32; got ", x.scalar_type());
+    TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kDouble, "molann_amd kernels are float32 / float64; got ",
+                x.scalar_type());
 }
 
 at::Tensor run_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
@@ -266,6 +272,27 @@ at::Tensor run_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::
     hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
     std::lock_guard<std::mutex> lock(e->mu);
     sync_live(*e, x, ref_x, weights, biases, stream);
+    if (x.scalar_type() == at::kDouble) { // `model.double()(x.double())`: the float64 entry points, forward only
+        const double* xd = x.data_ptr<double>();
+        double* od = out.data_ptr<double>();
+        if (e->kind == KIND_ALIGN) check(molann_align_f64(e->plan, xd, n, od, stream), "molann_align_f64");
+        else if (e->kind == KIND_FEATURES) check(molann_features_f64(e->plan, xd, n, od, stream), "molann_features_f64");
+        else {
+            TORCH_CHECK((int)weights.size() == e->n_layers && (int)biases.size() == e->n_layers, "molann::run: expected ", e->n_layers,
+                        " weight and bias tensors");
+            std::vector<at::Tensor> hold;
+            std::vector<const double*> W, B;
+            for (int l = 0; l < e->n_layers; ++l) {
+                TORCH_CHECK(weights[l].scalar_type() == at::kDouble && biases[l].scalar_type() == at::kDouble && weights[l].device() == x.device(),
+                            "molann::run: ann_layers must be float64 on ", x.device(), " for a float64 input");
+                hold.push_back(weights[l].detach().contiguous()); W.push_back(hold.back().data_ptr<double>());
+                hold.push_back(biases[l].detach().contiguous()); B.push_back(hold.back().data_ptr<double>());
+            }
+            at::Tensor work = at::empty({n, e->feature_dim}, x.options());
+            check(molann_forward_f64(e->plan, xd, n, W.data(), B.data(), work.data_ptr<double>(), od, stream), "molann_forward_f64");
+        }
+        return out;
+    }
     const float* xp = x.data_ptr<float>();
     float* op = out.data_ptr<float>();
     if (e->kind == KIND_ALIGN) check(molann_align_f32(e->plan, xp, n, op, stream), "molann_align_f32");
@@ -459,6 +486,14 @@ at::Tensor activation(int64_t code, const at::Tensor& t) {
 
 at::Tensor run_autograd(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
                         std::vector<at::Tensor> biases) {
+    if (x.scalar_type() == at::kDouble) { // float64 is forward only: never record a graph for it
+        bool needs = at::GradMode::is_enabled() && x.requires_grad();
+        for (const auto& w : weights) needs = needs || (at::GradMode::is_enabled() && w.requires_grad());
+        for (const auto& b : biases) needs = needs || (at::GradMode::is_enabled() && b.requires_grad());
+        TORCH_CHECK(!needs, "molann::run: the float64 kernels are forward only: call the float64 model under torch.no_grad()");
+        at::AutoDispatchBelowADInplaceOrView below;
+        return call_run(x, desc, ref_x, weights, biases);
+    }
     // A fused plan without a backward kernel (MLP wider than 32, large frames, ELU / GELU / Softplus) that has to
     // record gradients: features and their gradient from the kernels (the plan without the MLP), the MLP as ATen
     // ops - the composition molann_amd/ann.py: MolANN.forward uses in the same situation.

@@ -64,7 +64,7 @@ def test_scripted_empty_batch_and_bad_shapes(hip_device):
     assert loaded(torch.zeros(0, 22, 3, device=hip_device)).shape == (0, 3)
     with pytest.raises(RuntimeError, match="Input should be a 3d torch tensor"):
         loaded(torch.zeros(4, 21, 3, device=hip_device))
-    with pytest.raises(RuntimeError, match="float32"):
+    with pytest.raises(RuntimeError, match="float64"):
         loaded(torch.zeros(4, 22, 3, device=hip_device, dtype=torch.float64))
 
 
