@@ -1859,7 +1859,8 @@ std::string jit_preamble(const JitSpec& j) {
     s += (debug_env().ablate & 2048) ? "constexpr bool NO_COMPUTE = true;\n" : "constexpr bool NO_COMPUTE = false;\n";
     s += diag_env("MOLANN_DEBUG_TILE_CONTIG") ? "constexpr bool TILE_CONTIG = true;\n" : "constexpr bool TILE_CONTIG = false;\n"; // experiment
     s += diag_env("MOLANN_DEBUG_ST_NT") ? "constexpr bool ST_NT = true;\n" : "constexpr bool ST_NT = false;\n"; // experiment: non-temporal output stores
-    { const char* e = diag_env("MOLANN_DEBUG_SLEEP"); K("SLEEP_N", e ? atoi(e) : 0); } // with NO_COMPUTE: idle ~8k cycles x N per tile
+    { const char* e = diag_env("MOLANN_DEBUG_SLEEP"); K("SLEEP_N", e ? atoi(e) : 0); }
+    { const char* e = diag_env("MOLANN_DEBUG_SPIN"); K("SPIN_N", e ? atoi(e) : 0); }   // with NO_COMPUTE: 64 x N v_fma per tile // with NO_COMPUTE: idle ~8k cycles x N per tile
     auto A = [&](const char* name, const std::vector<int>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(b, sizeof(b), "%s%d", i ? ", " : "", v[i]); s += b; }

@@ -21,7 +21,7 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*_counters.csv"))):
         k = row.get("Kernel_Name", "")[:60]
         acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
 for k, ctrs in acc.items():
-    if "molann" not in k and "frames" not in k and "mlp" not in k and "lane_jit" not in k:
+    if "molann" not in k and "frames" not in k and "mlp" not in k and "lane_jit" not in k and "chain" not in k:
         continue
     print(k)
     for c, v in sorted(ctrs.items()):
