@@ -232,3 +232,46 @@ def test_mlp_behind_33_to_64_features_is_fused(n_feat, hip_device):
     xx = x[:100].double().requires_grad_(True)
     _oracle(model, xx, spec, False, align, wl.ALA_DIPEPTIDE_XYZ.astype(np.float32)).sum().backward()
     assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 5e-4 * float(xx.grad.abs().max())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_large_frame_plans_through_the_ring_kernel(seed, hip_device, monkeypatch):
+    """frames_ring_kernel (large frames: loader / consumer waves around an LDS ring of per-frame window images):
+    random frame sizes, touched-atom counts from a handful to > 2048 windows (where the plan falls back to
+    frames_wave_kernel), alignment sets, item mixes incl. positions at both ends of the frame, and batch sizes around
+    the ring's and the grid's sizes (1 frame, fewer frames than CUs, many frames per block) - against the fp64 oracle,
+    and bit for bit against frames_wave_kernel on the same plan."""
+    rng = np.random.default_rng(1000 + seed)
+    n_inp = int(rng.choice([120, 333, 1000, 2500, 5000]))
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    u = Universe(xyz)
+    n_feat = int(rng.choice([3, 40, 150, 700]))
+    spec, feats = [(3, [n_inp - 1, 0])], []
+    for i in range(n_feat):
+        t = int(rng.choice([0, 1, 2]))
+        k = NEED[t]
+        s0 = int(rng.integers(0, n_inp - k + 1))
+        atoms = list(range(s0, s0 + k)) if rng.random() < 0.7 else sorted(rng.choice(n_inp, size=k, replace=False).tolist())
+        spec.append((t, atoms))
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])) for i, (t, atoms) in enumerate(spec)]
+    uav = bool(rng.integers(0, 2))
+    align = sorted(rng.choice(np.arange(n_inp), size=int(rng.choice([3, 40, 300 if n_inp >= 333 else 50])), replace=False).tolist()) \
+        if seed % 3 != 2 else None
+    al = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms) if align is not None else None
+    pp = PreprocessingANN(al, FeatureLayer(feats, u.atoms, uav)).to(hip_device)
+    g = torch.Generator().manual_seed(seed)
+    for n in (1, 37, 300, 2111):
+        x = (torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)).float().contiguous()
+        with torch.no_grad():
+            got = pp(x.to(hip_device)).cpu()
+        info = last_launch_info(pp)
+        want = _oracle(pp, x, spec, uav, align, xyz)
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got.double() - want).abs().max()) <= 2e-5 * scale, (n, info)
+    assert "frames_ring_kernel" in info or "frames_wave_kernel" in info or "molann_lane_jit" in info, info
+    if "frames_ring_kernel" in info:
+        monkeypatch.setenv("MOLANN_NO_RING", "1")
+        with torch.no_grad():
+            old = pp(x.to(hip_device)).cpu()
+        assert "frames_wave_kernel" in last_launch_info(pp)
+        assert torch.equal(old, got)          # the same per-frame arithmetic on the same values
