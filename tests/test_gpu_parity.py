@@ -213,9 +213,12 @@ def test_cpu_tensor_and_grad_mode_fail_loudly(hip_device):
             model(x)                                  # CPU tensor: no fallback
     y = model(x.to(hip_device))                       # grad mode on: served by the backward-capable path
     assert y.requires_grad
-    with pytest.raises(TypeError):
+    with pytest.raises(RuntimeError):                  # float64 input, float32 module: mixed dtypes, as in the reference
         with torch.no_grad():
             model(x.to(hip_device).double())
+    with pytest.raises(TypeError):                     # neither float32 nor float64
+        with torch.no_grad():
+            model(x.to(hip_device).half())
 
 
 def test_capi_direct_forward_f32(hip_device):
