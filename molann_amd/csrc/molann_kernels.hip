@@ -743,6 +743,17 @@ __device__ __forceinline__ void ring_wait_frames(int k) { // at most k frames (N
     default: ring_wait_vmcnt<6 * ND>(); break;
     }
 }
+// LDS-DMA gather of 16 bytes per lane, saddr form: wave-uniform 64-bit base + the lane's zero-extended 32-bit offset ->
+// LDS (wave-uniform address in M0) + 16 * lane.  Inline asm: hipcc picks the vaddr form for `base + offset[i]` (a 64-bit
+// vector add per instruction on the loader's issue path); M0 is written where it is read and restored.  The loader
+// counts these operations itself (vmcnt).
+__device__ __forceinline__ void ring_dma16(const void* base_uniform, unsigned lane_off, unsigned lds_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(base_uniform), "s"(lds_uniform)
+                 : "memory");
+}
 typedef __attribute__((address_space(3))) volatile int* ring_word_t;
 __device__ __forceinline__ int ring_peek(ring_word_t w) { return __builtin_amdgcn_readfirstlane(*w); }
 
@@ -773,9 +784,9 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
     if (wave >= a.n_cons) {
         // =========================== loader ==========================================================
         __builtin_amdgcn_s_setprio(3);
-        int goff[ND];
+        unsigned goff[ND];
 #pragma unroll
-        for (int i = 0; i < ND; ++i) { const int w = 64 * i + lane; goff[i] = win_off[w < a.n_win ? w : 0]; }
+        for (int i = 0; i < ND; ++i) { const int w = 64 * i + lane; goff[i] = (unsigned)win_off[w < a.n_win ? w : 0]; }
         const int jl = wave - a.n_cons;
         int n_issue = jl, n_pub = jl, inflight = 0;
         while (n_pub < n_b) {
@@ -791,9 +802,9 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
                 const long f = (long)blockIdx.x + (long)n_issue * f_step;
                 const unsigned char* gsrc = (const unsigned char*)x + f * (long)a.frame_bytes;
                 unsigned char* slot = ring + (size_t)(n_issue % a.n_slot) * IMG_BYTES;
+                const unsigned slot_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)slot);
 #pragma unroll
-                for (int i = 0; i < ND; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + goff[i]), (lptr_t)(slot + (size_t)i * 1024), 16, 0, 0);
+                for (int i = 0; i < ND; ++i) ring_dma16(gsrc, goff[i], slot_lds + i * 1024);
                 n_issue += a.n_load;
                 ++inflight;
             } else {
