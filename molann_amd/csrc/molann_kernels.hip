@@ -1869,7 +1869,7 @@ std::string jit_preamble(const JitSpec& j) {
     // diagnostic (bit 2048): consumers hand every tile back as soon as it is in registers and compute nothing
     s += (debug_env().ablate & 2048) ? "constexpr bool NO_COMPUTE = true;\n" : "constexpr bool NO_COMPUTE = false;\n";
     s += diag_env("MOLANN_DEBUG_TILE_CONTIG") ? "constexpr bool TILE_CONTIG = true;\n" : "constexpr bool TILE_CONTIG = false;\n"; // experiment
-    s += diag_env("MOLANN_DEBUG_ST_NT") ? "constexpr bool ST_NT = true;\n" : "constexpr bool ST_NT = false;\n"; // experiment: non-temporal output stores
+    { const char* e = diag_env("MOLANN_DEBUG_ST_POLICY"); K("ST_POLICY", e ? atoi(e) : 1); } // cache policy of the output stores (1 = nt)
     { const char* e = diag_env("MOLANN_DEBUG_SLEEP"); K("SLEEP_N", e ? atoi(e) : 0); }
     { const char* e = diag_env("MOLANN_DEBUG_SPIN"); K("SPIN_N", e ? atoi(e) : 0); }   // with NO_COMPUTE: 64 x N v_fma per tile // with NO_COMPUTE: idle ~8k cycles x N per tile
     auto A = [&](const char* name, const std::vector<int>& v) {
