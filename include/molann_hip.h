@@ -185,12 +185,34 @@ int molann_plan_supports_backward(const molann_plan* plan);
 /* Gradients of molann_forward_packed_f32 (plans with an MLP) / molann_features_f32 (plans without) for the
  * same x: grad_out[N, out_dim] -> grad_x[N, n_inp, 3] (written; zeros for atoms the plan does not touch;
  * may be NULL) and grad_params (ACCUMULATED into with float atomics, so zero it first; may be NULL).
- * Nothing is saved from the forward: the kernel recomputes it.  Available for plans served by the
- * lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU / sigmoid / identity / SiLU /
- * LeakyReLU (compiled with hipRTC at the first call), and for feature plans without an MLP on large frames
- * (one wave per frame, float atomics into the zeroed gradient row); otherwise MOLANN_E_UNSUPPORTED. */
+ * Nothing is saved from the forward.  Plans with an MLP run three launches per chunk of frames - the features
+ * (recomputed into a workspace the plan allocates at its first backward), molann_mlp_backward_f32 and
+ * molann_features_backward_f32; a caller that kept the features of its forward (molann_features_f32 +
+ * molann_mlp_packed_f32 instead of the fused launch) calls those two itself and saves the recompute.
+ * Available for plans served by the lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU /
+ * sigmoid / identity / SiLU / LeakyReLU (kernels compiled with hipRTC at the first call), and for feature
+ * plans without an MLP on large frames (one wave per frame, float atomics into the zeroed gradient row);
+ * otherwise MOLANN_E_UNSUPPORTED. */
 int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* grad_x,
                         float* grad_params, molann_stream_t stream);
+
+/* molann_forward_packed_f32 that also writes features[N, feature_dim] (what molann_features_f32 would give), for a
+ * backward through molann_mlp_backward_f32 + molann_features_backward_f32 without the recompute.  Plans whose MLP
+ * is fused into the lane kernel (the ones molann_plan_supports_backward accepts with an MLP); same `out` bit for bit. */
+int molann_forward_train_f32(molann_plan* plan, const float* x, int64_t n_frames, float* out, float* features,
+                             molann_stream_t stream);
+
+/* dL/dx of molann_features_f32 (PreprocessingANN.forward ann.py:553-565) for the same x:
+ * grad_f[N, feature_dim] -> grad_x[N, n_inp, 3].  On a plan with an MLP this is the preprocessing half of its
+ * backward. */
+int molann_features_backward_f32(molann_plan* plan, const float* x, const float* grad_f, int64_t n_frames,
+                                 float* grad_x, molann_stream_t stream);
+
+/* Backward of molann_mlp_packed_f32 (create_sequential_nn's Sequential, ann.py:60-65) for the same f[N, layer_dims[0]]:
+ * grad_out[N, out_dim] -> grad_f[N, layer_dims[0]] (written; may be NULL) and grad_params (accumulated; may be NULL;
+ * layout of molann_plan_grad_params_size).  fp32 matrix cores; plans for which molann_plan_supports_backward is 1. */
+int molann_mlp_backward_f32(molann_plan* plan, const float* f, const float* grad_out, int64_t n_frames, float* grad_f,
+                            float* grad_params, molann_stream_t stream);
 
 /* -- misc ------------------------------------------------------------------------------------- */
 int molann_abi_version(void);

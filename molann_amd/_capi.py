@@ -97,6 +97,9 @@ def lib():
             "molann_plan_grad_params_size": (i32, [vp]),
             "molann_plan_supports_backward": (i32, [vp]),
             "molann_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
+            "molann_forward_train_f32": (i32, [vp, vp, i64, vp, vp, vp]),
+            "molann_features_backward_f32": (i32, [vp, vp, vp, i64, vp, vp]),
+            "molann_mlp_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_debug_read_stamps": (i32, [vp]),
             "molann_debug_jit": (i32, [ctypes.POINTER(PlanDesc), i32, ctypes.c_char_p, i32]),
             "molann_selftest_kabsch_rotation": (i32, [vp, ctypes.c_double, vp]),
@@ -272,6 +275,30 @@ class Plan(object):
                                         torch.cuda.current_stream().cuda_stream)
         if code != 0:
             raise MolannHipError(code, "molann_backward_f32")
+
+    def forward_train(self, x, out, features):
+        """`forward_packed` that also keeps the features (for `mlp_backward` + `features_backward`)."""
+        code = _lib.molann_forward_train_f32(self._handle, x.data_ptr(), x.shape[0], out.data_ptr(), features.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_forward_train_f32")
+        return out
+
+    def features_backward(self, x, grad_f, grad_x):
+        """dL/dx of `features` for the same x."""
+        code = _lib.molann_features_backward_f32(self._handle, x.data_ptr(), grad_f.data_ptr(), x.shape[0], grad_x.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_features_backward_f32")
+
+    def mlp_backward(self, f, grad_out, grad_f, grad_params):
+        """Backward of `mlp_packed` for the same f; grad_f / grad_params may be None; grad_params is accumulated into."""
+        code = _lib.molann_mlp_backward_f32(self._handle, f.data_ptr(), grad_out.data_ptr(), f.shape[0],
+                                            grad_f.data_ptr() if grad_f is not None else None,
+                                            grad_params.data_ptr() if grad_params is not None else None,
+                                            torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_mlp_backward_f32")
 
     def last_launch_info(self):
         buf = ctypes.create_string_buffer(256)

@@ -148,18 +148,31 @@ def _release_plans(desc, device):
 
 
 class _PlanFunction(torch.autograd.Function):
-    """forward = one fused launch of the plan; backward = molann_backward_f32 (recomputes the forward per
-    frame, nothing but x is saved).  `params` are the Linear weights/biases in layer order (may be empty)."""
+    """forward = one fused launch of the plan; with an MLP it also keeps the features (24 bytes per C3 frame), so that
+    the backward is two launches - the MLP's on the matrix cores (molann_mlp_backward_f32: dL/d features and the
+    parameter gradients), the preprocessing's (molann_features_backward_f32: recomputes Kabsch and the feature table
+    per frame from x).  `params` are the Linear weights/biases in layer order (may be empty)."""
 
     @staticmethod
     def forward(ctx, x, entry, with_mlp, *params):
         plan = entry.plan
         out = torch.empty((x.shape[0], plan.out_dim if with_mlp else plan.feature_dim), dtype=torch.float32, device=x.device)
+        feat = None
         if with_mlp:
-            plan.forward_packed(x, out)
+            feat = torch.empty((x.shape[0], plan.feature_dim), dtype=torch.float32, device=x.device)
+            try:
+                plan.forward_train(x, out, feat)
+            except _capi.MolannHipError as e:       # no feature-keeping twin of this plan's kernel: the backward recomputes
+                if e.code != _capi.E_UNSUPPORTED:
+                    raise
+                feat = None
+                plan.forward_packed(x, out)
         else:
             plan.features(x, out)
-        ctx.save_for_backward(x)
+        if feat is None:
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, feat)
         ctx.entry, ctx.shapes = entry, [tuple(p.shape) for p in params]
         return out
 
@@ -172,7 +185,8 @@ class _PlanFunction(torch.autograd.Function):
         if torch.is_grad_enabled():
             raise RuntimeError("molann_amd: the backward kernel is first-order only; create_graph=True (double "
                                "backward, e.g. a loss on forces) is not supported")
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
+        feat = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
         plan = ctx.entry.plan
         need_x = ctx.needs_input_grad[0]
         need_p = any(ctx.needs_input_grad[3:])
@@ -182,7 +196,13 @@ class _PlanFunction(torch.autograd.Function):
         if g.dtype != torch.float32:
             g = g.float()
         with torch.cuda.device(x.device):
-            plan.backward(x, g, gx, gp)
+            if feat is None:
+                plan.backward(x, g, gx, gp)
+            else:
+                gf = torch.empty_like(feat) if need_x else None
+                plan.mlp_backward(feat, g, gf, gp)
+                if need_x:
+                    plan.features_backward(x, gf, gx)
         grads, off = [], 0
         for i, shp in enumerate(ctx.shapes):
             n = 1

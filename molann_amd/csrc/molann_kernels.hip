@@ -993,6 +993,19 @@ __global__ __launch_bounds__(256) void mlp_f64_kernel(const double* __restrict__
 }
 
 // =============================================================================================
+// dst[i] += sum over rows of part[row][i]: the per-block parameter sums of molann_mlp_bwd (one writer per element)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < n_rows; r += 4) {
+        s0 += part[(long)r * n + i]; s1 += part[(long)(r + 1) * n + i]; s2 += part[(long)(r + 2) * n + i]; s3 += part[(long)(r + 3) * n + i];
+    }
+    for (; r < n_rows; ++r) s0 += part[(long)r * n + i];
+    dst[i] += (s0 + s1) + (s2 + s3);
+}
+
 // frames_wave_bwd_kernel: dL/dx of frames_wave_kernel (features of large frames), one wave per frame
 // =============================================================================================
 // grad_out[f][d_feat] -> grad_x[f][n_inp][3].  The frame's gradient row is zeroed with coalesced stores, then
@@ -1510,6 +1523,7 @@ struct molann_plan {
     hipStream_t last_stream;
     bool have_done;
     std::mutex* launch_mu;
+    std::mutex* jit_mu;        // the lazily built kernels (features twin, backward pair, backward workspace)
     int kp[MOLANN_MAX_LAYERS], jp[MOLANN_MAX_LAYERS];
     long moff[MOLANN_MAX_LAYERS];
     int mlp_ld[2], mlp_lds_per_wave;
@@ -1527,8 +1541,25 @@ struct molann_plan {
     char jit_note[96];
     struct JitSpecBox* spec;   // what the specialised kernels are generated from (kept for the lazy backward build)
     hipModule_t bwd_mod;
-    hipFunction_t bwd_fn;      // backward kernel, compiled at the first molann_backward_f32
+    hipFunction_t bwd_fn;      // backward of the preprocessing (molann_lane_bwd.inc), compiled at the first backward
     int bwd_state;             // 0 not tried, 1 ready, -1 unavailable
+    hipModule_t mbwd_mod;
+    hipFunction_t mbwd_fn;     // backward of the fused family's MLP (molann_mlp_bwd.inc), compiled at the first backward
+    int mbwd_state, mbwd_wpb;
+    // features-only twin of a forward kernel that has the MLP fused in (what molann_features_f32 and the backward's
+    // recompute launch on such a plan), compiled at the first use
+    hipModule_t train_mod;
+    hipFunction_t train_fn;    // the fused forward kernel that also writes the features (molann_forward_train_f32), same geometry
+    int train_state;
+    hipModule_t feat_mod;
+    hipFunction_t feat_fn;
+    int feat_state, feat_ncons, feat_nload, feat_nslot, feat_bpc, feat_lds_block;
+    float* d_gpart;            // molann_mlp_bwd's parameter sums, one row per block: [num_cus][n_grad_params]
+    hipEvent_t ev_bwork;       // the backward workspaces (d_gpart, d_bwork) are shared by all streams: see launch_mu
+    hipStream_t bwork_stream;
+    bool have_bwork;
+    float* d_bwork;            // molann_backward_f32 on a plan with an MLP: features and their gradient, [2][bwork_frames][d_feat]
+    long bwork_frames;
     int n_grad_params;         // floats of the parameter-gradient buffer (dW_l[J][K], db_l[J] per layer)
     // plan-specialised wide bf16 MLP (molann_mlp_jit.inc); nullptr -> mlp_mfma_kernel<bf16>
     hipModule_t chain_mod;
@@ -1694,6 +1725,7 @@ struct JitSpec { // what the specialised kernel is compiled for
     int n_inp, n_align, n_layers, act, d_feat, out_cols, wpb, lds_per_wave, fbuf_off;
     int waves_per_eu = 2;             // occupancy the backward kernel is compiled for (amdgpu_waves_per_eu)
     int nbuf = 1;
+    bool save_feat = false;           // forward kernel: also writes the features (training; molann_forward_train_f32)
     // forward kernel: loader / consumer block around a ring of tile slots (molann_lane_jit.inc)
     int nload = 1;                    // loaders per block
     int ncons = 0, nslot = 0, depth = 0, ring_off = 0, tile_stride = 0, fb_off = 0, fb_bytes = 0, lds_block = 0, bpc = 0;
@@ -1798,29 +1830,53 @@ std::string jit_source_chain(const ChainGeom& g, int act, int fb) {
     return s;
 }
 
-// backward kernel: the forward preamble + where the weights live (fp32 MFMA copy: Wp[Jp][Kp], bias[Jp]) and
-// the layout of the parameter-gradient buffer (torch layout: dW[J][K] then db[J], layer after layer)
+// backward of the preprocessing: the forward preamble of the plan without its MLP
 std::string jit_source_bwd(const JitSpecBox& b, int lds_per_wave) {
     JitSpec j = b.j;
     j.lds_per_wave = lds_per_wave;
+    j.n_layers = 0;
+    j.out_cols = j.d_feat;
+    j.dims.clear();
     std::string s = jit_preamble(j);
+    s += "#line 1 \"molann_lane_bwd.inc\"\n";
+    s += join_chunks(k_src_molann_lane_bwd_inc);
+    return s;
+}
+
+// rows of the [unit][frame] scratch of molann_mlp_bwd.inc (the kernel text computes the same number: n_rows())
+int mlp_bwd_rows(const std::vector<int>& dims, int act) {
+    const int nl = (int)dims.size() - 1;
+    auto pad4 = [](int v) { return (v + 3) & ~3; };
+    auto b16 = [](int v) { return (v + 15) >> 4; };
+    auto act_row = [&](int l) { int r = 0; for (int i = 0; i < l; ++i) r += pad4(dims[i]); return r; };
+    auto z_row = [&](int l) { int r = act_row(nl); for (int i = 0; i < l; ++i) r += pad4(dims[i + 1]); return r; };
+    const int z_end = act == 5 ? z_row(nl - 1) : act_row(nl);
+    auto d_row = [&](int l) { int r = z_end; for (int i = nl - 1; i > l; --i) r += pad4(dims[i + 1]); return r; };
+    int m = d_row(0) + pad4(dims[1]);
+    for (int l = 0; l < nl; ++l) m = std::max(m, std::max(act_row(l) + 16 * b16(dims[l]), d_row(l) + 16 * b16(dims[l + 1])));
+    return m;
+}
+
+// backward of the MLP: layer widths, activation, where the weights live (fp32 MFMA copy: Wp[Jp][Kp], bias[Jp]) and
+// the layout of the parameter-gradient buffer (torch layout: dW[J][K] then db[J], layer after layer)
+std::string jit_source_mlp_bwd(const JitSpecBox& b, int wpb) {
+    const JitSpec& j = b.j;
+    std::string s = "// preamble generated from the plan\n";
     char t[128];
+    auto K = [&](const char* name, int v) { snprintf(t, sizeof(t), "constexpr int %s = %d;\n", name, v); s += t; };
     auto arr = [&](const char* name, const std::vector<long>& v) {
         s += std::string("constexpr int ") + name + "[] = {";
         for (size_t i = 0; i < v.size(); ++i) { snprintf(t, sizeof(t), "%s%ld", i ? ", " : "", v[i]); s += t; }
         s += "};\n";
     };
-    std::vector<long> kp(b.kp.begin(), b.kp.end()), jp(b.jp.begin(), b.jp.end()), woff = b.woff, goff;
+    K("NL", j.n_layers); K("ACT", j.act); K("WPB_M", wpb);
+    std::vector<long> dims(j.dims.begin(), j.dims.end()), kp(b.kp.begin(), b.kp.end()), jp(b.jp.begin(), b.jp.end()), woff = b.woff, goff;
     long g = 0;
     for (int l = 0; l < j.n_layers; ++l) { goff.push_back(g); g += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1]; }
-    if (kp.empty()) { kp.push_back(1); jp.push_back(1); woff.push_back(0); goff.push_back(0); }
-    arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
-    snprintf(t, sizeof(t), "constexpr int N_PARAMS = %ld;\n", g);
-    s += t;
-    // diagnostic (MOLANN_DEBUG_ABLATE bit 1024): constants instead of the scalar weight loads (results are wrong)
-    s += (debug_env().ablate & 1024) ? "constexpr bool FAKE_W = true;\n" : "constexpr bool FAKE_W = false;\n";
-    s += "#line 1 \"molann_lane_bwd.inc\"\n";
-    s += join_chunks(k_src_molann_lane_bwd_inc);
+    arr("DIMS", dims); arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
+    K("N_PARAMS", (int)g);
+    s += "#line 1 \"molann_mlp_bwd.inc\"\n";
+    s += join_chunks(k_src_molann_mlp_bwd_inc);
     return s;
 }
 
@@ -1834,6 +1890,7 @@ std::string jit_preamble(const JitSpec& j) {
     K("WAVES_PER_EU", j.waves_per_eu); K("NBUF", j.nbuf);
     K("NCONS", j.ncons); K("NLOAD", j.nload); K("LDS_BLOCK", j.lds_block); K("NSLOT", j.nslot); K("DEPTH", j.depth); K("RING_OFF", j.ring_off); K("TILE_STRIDE", j.tile_stride);
     K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes);
+    s += j.save_feat ? "constexpr bool SAVE_FEAT = true;\n" : "constexpr bool SAVE_FEAT = false;\n";
     {   // waves per SIMD the forward kernel must fit (its register budget): every wave of the (NCONS + 1)-wave blocks
         // a CU is to hold - the loader waves carry the consumers' allocation
         const int waves = (j.ncons + j.nload) * std::max(1, j.bpc);
@@ -1939,28 +1996,76 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
 
 // preprocessing (align / features / fused forward) for n_frames starting at x -> out
 int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mode, bool with_mlp,
-               hipStream_t stream) {
+               hipStream_t stream, float* feat_out = nullptr) {
     const int out_cols = mode == 1 ? 0 : (with_mlp ? p->out_dim : p->d_feat);
     PreArgs a;
     fill_pre_args(p, a, n_frames, mode, out_cols, with_mlp, x, out);
     // the plan-specialised lane kernel first: it serves every plan it was built for, including few-atom plans on
     // frames too large for the ahead-of-time lane kernel's dense tile
-    if (mode == 0 && p->jit_fn && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024 | 2048)) == 0 && p->jit_nl == (with_mlp ? p->n_layers : 0)) {
+    const bool jit_allowed = mode == 0 && (a.ablate & ~(32 | 64 | 128 | 256 | 512 | 1024 | 2048)) == 0;
+    auto launch_jit = [&](hipFunction_t fn, int nl, int ncons, int nload, int nslot, int bpc, int lds_block) {
         const long n_tiles = (n_frames + 63) / 64;
-        const int jgrid = grid_for(p, n_tiles, 1, p->jit_bpc);   // every block needs at least one tile
+        const int jgrid = grid_for(p, n_tiles, 1, bpc);   // every block needs at least one tile
         const size_t jlds = (size_t)debug_env().lds_pad;   // the kernel declares its block's LDS statically
         unsigned long long* stamps = nullptr;
         if (a.ablate & 32) (void)hipGetSymbolAddress((void**)&stamps, HIP_SYMBOL(g_stamps));
         struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int out_vec4, pad_;
-                 unsigned long long* stamps; const float* ref32; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.out_vec4, 0,
-                                                                        stamps, p->d_ref};
+                 unsigned long long* stamps; const float* ref32; float* feat; } ka = {x, out, p->d_ref64, p->d_wlane, n_frames, a.out_vec4, 0,
+                                                                                     stamps, p->d_ref, feat_out};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-        const int jblock = 64 * (p->jit_ncons + p->jit_nload);
-        const hipError_t le = hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, jblock, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
+        const int jblock = 64 * (ncons + nload);
+        const hipError_t le = hipModuleLaunchKernel(fn, jgrid, 1, 1, jblock, 1, 1, (unsigned)jlds, stream, nullptr, cfg);
         snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<NL=%d> (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d",
-                 p->jit_nl, p->jit_ncons, p->jit_nload, p->jit_nslot, jgrid, jblock, p->jit_lds_block);
+                 nl, ncons, nload, nslot, jgrid, jblock, lds_block);
         return (int)le;
+    };
+    if (feat_out) { // training forward: the fused kernel's twin that keeps the features, built now
+        if (!(jit_allowed && with_mlp && p->jit_fn && p->jit_nl == p->n_layers && p->jit_nl > 0 && p->spec)) return MOLANN_E_UNSUPPORTED;
+        if (p->train_state == 0) {
+            std::lock_guard<std::mutex> lock(*p->jit_mu);
+            if (p->train_state == 0) {
+                JitSpec j = p->spec->j;
+                j.save_feat = true;
+                std::vector<char> code;
+                std::string log;
+                int st = -1;
+                if (jit_compile(jit_source(j), code, log, "-fno-slp-vectorize") == 0 && hipModuleLoadData(&p->train_mod, code.data()) == hipSuccess &&
+                    hipModuleGetFunction(&p->train_fn, p->train_mod, "molann_lane_jit") == hipSuccess)
+                    st = 1;
+                else if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann training-forward jit failed\n%s\n", log.c_str());
+                p->train_state = st;
+            }
+        }
+        if (p->train_state != 1) return MOLANN_E_UNSUPPORTED;
+        return launch_jit(p->train_fn, p->jit_nl, p->jit_ncons, p->jit_nload, p->jit_nslot, p->jit_bpc, p->jit_lds_block);
+    }
+    if (jit_allowed && p->jit_fn && p->jit_nl == (with_mlp ? p->n_layers : 0))
+        return launch_jit(p->jit_fn, p->jit_nl, p->jit_ncons, p->jit_nload, p->jit_nslot, p->jit_bpc, p->jit_lds_block);
+    if (jit_allowed && !with_mlp && p->jit_fn && p->jit_nl > 0 && p->spec && p->feat_state >= 0) {
+        // features of a plan whose forward kernel has the MLP fused in: the same kernel text without the MLP, built now
+        if (p->feat_state == 0) {
+            std::lock_guard<std::mutex> lock(*p->jit_mu);
+            if (p->feat_state == 0) {
+                JitSpec j = p->spec->j;
+                j.n_layers = 0; j.out_cols = j.d_feat; j.dims.clear();
+                molann_plan::LaneGeom g;
+                memset(&g, 0, sizeof(g));
+                jit_geometry(j, g, std::max(1, j.d_feat), std::max(1, j.d_feat));
+                std::vector<char> code;
+                std::string log;
+                int st = -1;
+                if (g.ok && jit_compile(jit_source(j), code, log, "-fno-slp-vectorize") == 0 &&
+                    hipModuleLoadData(&p->feat_mod, code.data()) == hipSuccess &&
+                    hipModuleGetFunction(&p->feat_fn, p->feat_mod, "molann_lane_jit") == hipSuccess) {
+                    p->feat_ncons = j.ncons; p->feat_nload = j.nload; p->feat_nslot = j.nslot; p->feat_bpc = j.bpc; p->feat_lds_block = j.lds_block;
+                    st = 1;
+                } else if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann features jit failed\n%s\n", log.c_str());
+                p->feat_state = st;
+            }
+        }
+        if (p->feat_state == 1)
+            return launch_jit(p->feat_fn, 0, p->feat_ncons, p->feat_nload, p->feat_nslot, p->feat_bpc, p->feat_lds_block);
     }
     const molann_plan::LaneGeom& g = p->geom[mode == 1 ? 1 : 0];
     if (mode == 0 && p->jit_only && (with_mlp || !g.ok)) return MOLANN_E_UNSUPPORTED; // served by the specialised kernel only, and a diagnostic switch excluded it
@@ -2173,6 +2278,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     if (!p) return (int)hipErrorOutOfMemory;
     memset(p, 0, sizeof(*p));
     p->launch_mu = new std::mutex();
+    p->jit_mu = new std::mutex();
     p->device = dev;
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     p->n_inp = d->n_inp;
@@ -2514,6 +2620,12 @@ int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
     if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
+    if (p->mbwd_mod) (void)hipModuleUnload(p->mbwd_mod);
+    if (p->feat_mod) (void)hipModuleUnload(p->feat_mod);
+    if (p->train_mod) (void)hipModuleUnload(p->train_mod);
+    if (p->d_bwork) (void)hipFree(p->d_bwork);
+    if (p->d_gpart) (void)hipFree(p->d_gpart);
+    if (p->ev_bwork) (void)hipEventDestroy(p->ev_bwork);
     if (p->chain_mod) (void)hipModuleUnload(p->chain_mod);
     delete p->spec;
     if (p->side) {
@@ -2523,6 +2635,7 @@ int molann_plan_destroy(molann_plan* p) {
         (void)hipStreamDestroy(p->side);
     }
     delete p->launch_mu;
+    delete p->jit_mu;
     hipError_t e = hipFree(p->blob);
     delete p;
     return (int)e;
@@ -2683,6 +2796,19 @@ int molann_forward_f32(molann_plan* p, const float* x, int64_t n, const float* c
     return molann_forward_packed_f32(p, x, n, out, stream);
 }
 
+// The fused forward that also keeps the features, for a backward that does not recompute them
+int molann_forward_train_f32(molann_plan* p, const float* x, int64_t n, float* out, float* features, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (p->n_layers <= 0 || p->n_items <= 0) return MOLANN_E_STAGE;
+    if (!p->fused_mlp) return MOLANN_E_UNSUPPORTED;
+    if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    const int c = check_io(x, out, n);
+    if (c != MOLANN_OK || n == 0) return c;
+    if (!features) return MOLANN_E_NULL;
+    if (((uintptr_t)features) & 3) return MOLANN_E_ALIGNMENT;
+    return launch_pre(p, x, (long)n, out, 0, true, (hipStream_t)stream, features);
+}
+
 
 // ---- float64 entry points (the reference's modules follow x.dtype) -------------------------------------------------
 static int check_io_f64(const void* x, const void* out, int64_t n) {
@@ -2758,11 +2884,123 @@ int molann_plan_supports_backward(const molann_plan* p) {
     if (!p) return MOLANN_E_NULL;
     if (!p->geom[0].ok) return (p->n_items > 0 && p->n_layers == 0) ? 1 : 0; // large frames: features only (frames_wave_bwd_kernel)
     if (!p->spec || p->n_items <= 0 || p->bwd_state < 0 || !rtc_api()->ok) return 0;
-    if (p->n_layers > 0 && (!p->fused_mlp || p->d_feat > LANE_MLP_MAX_WIDTH)) return 0;
+    if (p->n_layers > 0 && (!p->fused_mlp || p->d_feat > LANE_MLP_MAX_WIDTH || p->mbwd_state < 0)) return 0;
     const int act = p->act;
     if (p->n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return 0;
     return 1;
 }
+
+namespace {
+// ---- backward: lazily built kernels and workspaces --------------------------------------------------------------------
+// The workspaces (parameter partial sums, recomputed features) belong to the plan and are shared by all streams: the
+// enqueue is serialised by launch_mu and a caller on another stream first waits for the event recorded behind the
+// previous backward (the protocol of the unfused forward).
+struct BwdGuard {
+    molann_plan* p;
+    hipStream_t s;
+    std::unique_lock<std::mutex> lock;
+    int rc;
+    BwdGuard(molann_plan* plan, hipStream_t stream) : p(plan), s(stream), lock(*plan->launch_mu), rc(0) {
+        if (p->have_bwork && p->bwork_stream != s) rc = (int)hipStreamWaitEvent(s, p->ev_bwork, 0);
+    }
+    ~BwdGuard() {
+        if (hipEventRecord(p->ev_bwork, s) == hipSuccess) { p->have_bwork = true; p->bwork_stream = s; }
+    }
+};
+
+int ensure_bwd_event(molann_plan* p) { // jit_mu held
+    if (!p->ev_bwork) HIP_TRY(hipEventCreateWithFlags(&p->ev_bwork, hipEventDisableTiming));
+    return MOLANN_OK;
+}
+
+int ensure_mlp_bwd(molann_plan* p) {
+    if (p->mbwd_state == 0 || !p->d_gpart) {
+        std::lock_guard<std::mutex> lock(*p->jit_mu);
+        if (p->mbwd_state == 0) {
+            const int rows = mlp_bwd_rows(p->spec->j.dims, p->act);
+            const int wpb = (int)std::min<long>(8, (163840 - 64) / ((long)rows * 68 * 4));
+            std::vector<char> code;
+            std::string log;
+            int rc = -1;
+            if (wpb >= 1) rc = jit_compile(jit_source_mlp_bwd(*p->spec, wpb), code, log);
+            if (rc == 0 && hipModuleLoadData(&p->mbwd_mod, code.data()) == hipSuccess &&
+                hipModuleGetFunction(&p->mbwd_fn, p->mbwd_mod, "molann_mlp_bwd") == hipSuccess) {
+                p->mbwd_wpb = wpb;
+                p->mbwd_state = 1;
+            } else {
+                p->mbwd_state = -1;
+                if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann mlp backward jit failed rc=%d\n%s\n", rc, log.c_str());
+            }
+        }
+        if (p->mbwd_state == 1 && !p->d_gpart) {
+            { const int er = ensure_bwd_event(p); if (er != MOLANN_OK) return er; }
+            HIP_TRY(hipMalloc((void**)&p->d_gpart, (size_t)p->num_cus * std::max(1, p->n_grad_params) * 4));
+        }
+    }
+    return p->mbwd_state == 1 ? MOLANN_OK : MOLANN_E_UNSUPPORTED;
+}
+
+int ensure_features_bwd(molann_plan* p, molann_plan::LaneGeom& g) {
+    lane_geometry(g, 64 * p->n_inp * 12, 1); // the dense frame tile (reused for the gradient rows)
+    if (!g.ok) return MOLANN_E_UNSUPPORTED;
+    if (p->bwd_state == 0) {
+        std::lock_guard<std::mutex> lock(*p->jit_mu);
+        if (p->bwd_state == 0) {
+            std::vector<char> code;
+            std::string log;
+            JitSpecBox b = *p->spec;
+            b.j.wpb = g.wpb;
+            const int rc = jit_compile(jit_source_bwd(b, g.lds_per_wave), code, log);
+            if (rc == 0 && hipModuleLoadData(&p->bwd_mod, code.data()) == hipSuccess &&
+                hipModuleGetFunction(&p->bwd_fn, p->bwd_mod, "molann_lane_bwd") == hipSuccess) {
+                p->bwd_state = 1;
+            } else {
+                p->bwd_state = -1;
+                if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann backward jit failed rc=%d\n%s\n", rc, log.c_str());
+            }
+        }
+    }
+    return p->bwd_state == 1 ? MOLANN_OK : MOLANN_E_UNSUPPORTED;
+}
+
+// molann_lane_bwd: grad_f -> grad_x (no workspace)
+int launch_features_bwd(molann_plan* p, const molann_plan::LaneGeom& g, const float* x, const float* grad_f, long n, float* grad_x,
+                        hipStream_t stream) {
+    const long n_tiles = (n + 63) / 64;
+    int bpc = (int)(163840 / ((long)g.wpb * g.lds_per_wave));
+    if (bpc < 1) bpc = 1;
+    if (bpc * g.wpb > 8) bpc = std::max(1, 8 / g.wpb);
+    const int grid = grid_for(p, n_tiles, g.wpb, bpc);
+    struct { const float* x; const float* gf; const double* ref64; float* gx; long n; int x_wide; } ka =
+        {x, grad_f, p->d_ref64, grad_x, n, (((uintptr_t)x) & 15) == 0 ? 1 : 0};
+    size_t ksz = sizeof(ka);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+    const hipError_t le = hipModuleLaunchKernel(p->bwd_fn, grid, 1, 1, 64 * g.wpb, 1, 1, (unsigned)((size_t)g.wpb * g.lds_per_wave), stream,
+                                                nullptr, cfg);
+    snprintf(p->last_info, sizeof(p->last_info), "molann_lane_bwd (plan-specialised) grid=%d block=%d", grid, 64 * g.wpb);
+    return (int)le;
+}
+
+// molann_mlp_bwd (+ reduce_rows_kernel when parameter gradients are wanted); the caller holds the workspace (BwdGuard)
+int launch_mlp_bwd(molann_plan* p, const float* f, const float* grad_out, long n, float* grad_f, float* grad_params, hipStream_t stream) {
+    const long n_tiles = (n + 63) / 64;
+    const int grid = (int)std::max<long>(1, std::min<long>(p->num_cus, (n_tiles + p->mbwd_wpb - 1) / p->mbwd_wpb)); // one block per CU
+    struct { const float* f; const float* gout; const float* wnat; float* gf; float* gp; long n; } ka =
+        {f, grad_out, (const float*)p->d_wmfma, grad_f, grad_params ? p->d_gpart : nullptr, n};
+    size_t ksz = sizeof(ka);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+    const hipError_t le = hipModuleLaunchKernel(p->mbwd_fn, grid, 1, 1, 64 * p->mbwd_wpb, 1, 1, 0, stream, nullptr, cfg);
+    if (le != hipSuccess) return (int)le;
+    if (grad_params) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((p->n_grad_params + 255) / 256), dim3(256), 0, stream, p->d_gpart, grid, p->n_grad_params,
+                           grad_params);
+        HIP_TRY(hipGetLastError());
+    }
+    snprintf(p->last_info, sizeof(p->last_info), "molann_mlp_bwd (plan-specialised) grid=%d block=%d%s", grid, 64 * p->mbwd_wpb,
+             grad_params ? " + reduce_rows_kernel" : "");
+    return MOLANN_OK;
+}
+} // namespace
 
 // dL/dx and dL/d(parameters) of molann_forward_packed_f32 / molann_features_f32 for the same x.
 int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, int64_t n, float* grad_x, float* grad_params,
@@ -2784,41 +3022,86 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
         return (int)hipGetLastError();
     }
     if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
-    const int act = p->act;
-    if (p->spec->j.n_layers > 0 && !(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 7)) return MOLANN_E_UNSUPPORTED;
-    if (p->n_layers > 0 && (!p->fused_mlp || p->d_feat > LANE_MLP_MAX_WIDTH)) return MOLANN_E_UNSUPPORTED; // wide MLPs / > 32 features
-    if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    if (p->n_layers == 0) return molann_features_backward_f32(p, x, grad_out, n, grad_x, stream);
+    // plans with an MLP, nothing saved from the forward: features (recomputed) -> MLP backward -> preprocessing backward,
+    // in chunks through the plan's backward workspace (allocated at the first call, like the kernels are compiled then)
+    if (!molann_plan_supports_backward(p)) return MOLANN_E_UNSUPPORTED;
+    if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_x) & 3) || (((uintptr_t)grad_params) & 3)) return MOLANN_E_ALIGNMENT;
+    if (!grad_x && !grad_params) return MOLANN_OK;
     molann_plan::LaneGeom g;
-    lane_geometry(g, std::max(64 * p->n_inp * 12, 64 * 68 * 4), 1); // frame tile, reused as the [unit][frame] scratch
-    if (!g.ok) return MOLANN_E_UNSUPPORTED;
-    if (p->bwd_state == 0) {
-        std::vector<char> code;
-        std::string log;
-        JitSpecBox b = *p->spec;
-        b.j.wpb = g.wpb;
-        const int rc = jit_compile(jit_source_bwd(b, g.lds_per_wave), code, log);
-        if (rc == 0 && hipModuleLoadData(&p->bwd_mod, code.data()) == hipSuccess &&
-            hipModuleGetFunction(&p->bwd_fn, p->bwd_mod, "molann_lane_bwd") == hipSuccess) {
-            p->bwd_state = 1;
-        } else {
-            p->bwd_state = -1;
-            if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann backward jit failed rc=%d\n%s\n", rc, log.c_str());
+    int rc = ensure_mlp_bwd(p);
+    if (rc == MOLANN_OK && grad_x) rc = ensure_features_bwd(p, g);
+    if (rc != MOLANN_OK) return rc;
+    if (!p->d_bwork) {
+        std::lock_guard<std::mutex> lock(*p->jit_mu);
+        if (!p->d_bwork) {
+            long bf = std::min<long>(1l << 20, (64l << 20) / ((long)p->d_feat * 4)) & ~63l;
+            bf = std::max<long>(bf, 4096);
+            float* w = nullptr;
+            HIP_TRY(hipMalloc((void**)&w, 2 * (size_t)bf * p->d_feat * 4));
+            p->bwork_frames = bf;
+            p->d_bwork = w;
         }
     }
-    if (p->bwd_state != 1) return MOLANN_E_UNSUPPORTED;
-    const long n_tiles = (n + 63) / 64;
-    int bpc = (int)(163840 / ((long)g.wpb * g.lds_per_wave));
-    if (bpc < 1) bpc = 1;
-    if (bpc * g.wpb > 8) bpc = std::max(1, 8 / g.wpb);
-    const int grid = grid_for(p, n_tiles, g.wpb, bpc);
-    struct { const float* x; const float* gout; const double* ref64; const float* wnat; float* gx; float* gp; long n; int x_wide; } ka =
-        {x, grad_out, p->d_ref64, (const float*)p->d_wmfma, grad_x, grad_params, (long)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0};
-    size_t ksz = sizeof(ka);
-    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-    const hipError_t le = hipModuleLaunchKernel(p->bwd_fn, grid, 1, 1, 64 * g.wpb, 1, 1, (unsigned)((size_t)g.wpb * g.lds_per_wave),
-                                                (hipStream_t)stream, nullptr, cfg);
-    snprintf(p->last_info, sizeof(p->last_info), "molann_lane_bwd (plan-specialised) grid=%d block=%d", grid, 64 * g.wpb);
-    return (int)le;
+    hipStream_t main = (hipStream_t)stream;
+    BwdGuard guard(p, main);
+    if (guard.rc != 0) return guard.rc;
+    float* wf = p->d_bwork;
+    float* wg = p->d_bwork + (size_t)p->bwork_frames * p->d_feat;
+    char info[3][96];
+    info[0][0] = info[1][0] = info[2][0] = 0;
+    for (int64_t s = 0; s < n && rc == MOLANN_OK; s += p->bwork_frames) {
+        const long m = (long)std::min<int64_t>(p->bwork_frames, n - s);
+        const float* xs = x + s * (long)p->n_inp * 3;
+        if ((rc = launch_pre(p, xs, m, wf, 0, false, main)) != 0) break;
+        if (s == 0) snprintf(info[0], sizeof(info[0]), "%.95s", p->last_info);
+        if ((rc = launch_mlp_bwd(p, wf, grad_out + s * (long)p->out_dim, m, grad_x ? wg : nullptr, grad_params, main)) != 0) break;
+        if (s == 0) snprintf(info[1], sizeof(info[1]), "%.95s", p->last_info);
+        if (grad_x && (rc = launch_features_bwd(p, g, xs, wg, m, grad_x + s * (long)p->n_inp * 3, main)) != 0) break;
+        if (s == 0 && grad_x) snprintf(info[2], sizeof(info[2]), "%.95s", p->last_info);
+    }
+    if (rc == MOLANN_OK) snprintf(p->last_info, sizeof(p->last_info), "%.80s || %.80s || %.80s", info[0], info[1], info[2]);
+    return rc;
+}
+
+// dL/dx of molann_features_f32 for the same x: grad_f[N, feature_dim] -> grad_x[N, n_inp, 3]
+int molann_features_backward_f32(molann_plan* p, const float* x, const float* grad_f, int64_t n, float* grad_x, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !grad_f) return MOLANN_E_NULL;
+    if (!p->geom[0].ok) { // large frames: the wave-per-frame kernel (plans without an MLP)
+        if (p->n_items <= 0 || p->n_layers != 0) return MOLANN_E_UNSUPPORTED;
+        return molann_backward_f32(p, x, grad_f, n, grad_x, nullptr, stream);
+    }
+    if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
+    if (!grad_x) return MOLANN_OK;
+    if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_f) & 3) || (((uintptr_t)grad_x) & 3)) return MOLANN_E_ALIGNMENT;
+    molann_plan::LaneGeom g;
+    const int rc = ensure_features_bwd(p, g);
+    if (rc != MOLANN_OK) return rc;
+    return launch_features_bwd(p, g, x, grad_f, (long)n, grad_x, (hipStream_t)stream);
+}
+
+// dL/df and dL/d(parameters) of molann_mlp_packed_f32 for the same f (the fused family: every width <= 32)
+int molann_mlp_backward_f32(molann_plan* p, const float* f, const float* grad_out, int64_t n, float* grad_f, float* grad_params,
+                            molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!f || !grad_out) return MOLANN_E_NULL;
+    if (p->n_layers <= 0) return MOLANN_E_STAGE;
+    if (!p->spec || !molann_plan_supports_backward(p)) return MOLANN_E_UNSUPPORTED;
+    if (!p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    if ((((uintptr_t)f) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_f) & 3) || (((uintptr_t)grad_params) & 3)) return MOLANN_E_ALIGNMENT;
+    if (!grad_f && !grad_params) return MOLANN_OK;
+    const int rc = ensure_mlp_bwd(p);
+    if (rc != MOLANN_OK) return rc;
+    if (!grad_params) return launch_mlp_bwd(p, f, grad_out, (long)n, grad_f, nullptr, (hipStream_t)stream); // no workspace involved
+    BwdGuard guard(p, (hipStream_t)stream);
+    if (guard.rc != 0) return guard.rc;
+    return launch_mlp_bwd(p, f, grad_out, (long)n, grad_f, grad_params, (hipStream_t)stream);
 }
 
 // diagnostic / test hook: generate (and optionally compile, needs no GPU) the plan-specialised kernel
@@ -2895,10 +3178,19 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
             off += (long)jp * kp + jp;
             off = (off + 3) & ~3l;
         }
-        molann_plan::LaneGeom gb;
-        lane_geometry(gb, std::max(64 * d->n_inp * 12, 64 * 68 * 4), 1);
-        b.j.wpb = gb.wpb;
-        src = jit_source_bwd(b, gb.lds_per_wave);
+        if (do_compile & 8) { // ... its MLP half (molann_mlp_bwd.inc)
+            if (j.n_layers <= 0) return MOLANN_E_STAGE;
+            for (int v : j.dims) if (v > 32) return MOLANN_E_UNSUPPORTED;
+            const int rows = mlp_bwd_rows(j.dims, j.act);
+            const int wpb = (int)std::min<long>(8, (163840 - 64) / ((long)rows * 68 * 4));
+            if (wpb < 1) return MOLANN_E_UNSUPPORTED;
+            src = jit_source_mlp_bwd(b, wpb);
+        } else {             // ... its preprocessing half (molann_lane_bwd.inc)
+            molann_plan::LaneGeom gb;
+            lane_geometry(gb, 64 * d->n_inp * 12, 1);
+            b.j.wpb = gb.wpb;
+            src = jit_source_bwd(b, gb.lds_per_wave);
+        }
     }
     if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", src.c_str());
     if (do_compile & 1) {

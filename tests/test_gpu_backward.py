@@ -238,3 +238,94 @@ def test_wide_mlp_trains_through_hip_features(act, hip_device):
                      [(l.bias.grad, b.grad) for l, b in zip(lins, bs)]:
         scale = max(1e-6, float(want.abs().max()))
         assert float((got.cpu().double() - want).abs().max()) <= 2e-4 * scale
+
+
+# ---- the halves of the backward through the C ABI (molann_forward_train_f32, molann_mlp_backward_f32,
+# molann_features_backward_f32) -------------------------------------------------------------------------------------------
+def _c3_plan(model, x):
+    """The ctypes plan of a MolANN (weights packed by a first forward + backward)."""
+    model(x).sum().backward()
+    for p in model.parameters():
+        p.grad = None
+    return model._fast_state(x)["entry"]().plan
+
+
+@pytest.mark.parametrize("dims,act", [([6, 32, 8], torch.nn.Tanh), ([6, 32, 32, 3], torch.nn.Tanh), ([6, 17, 5, 9, 2], torch.nn.Sigmoid),
+                                      ([6, 4], torch.nn.Tanh), ([6, 30, 31], torch.nn.SiLU), ([6, 24, 24, 1], torch.nn.ReLU),
+                                      ([6, 32, 32, 32, 32], torch.nn.LeakyReLU)])
+@pytest.mark.parametrize("n", [1, 64, 777])
+def test_mlp_backward_kernel_vs_fp64_autograd(dims, act, n, hip_device):
+    """molann_mlp_backward_f32 alone: grad_f and the parameter gradients of ann_layers on given features."""
+    import copy
+    w = wl.get_workload("C3")
+    base = wl.build_model(w, hip_device)
+    torch.manual_seed(len(dims) * 100 + n)
+    model = MolANN(base.preprocessing_layer, create_sequential_nn(dims, activation=act()).to(hip_device))
+    x = w.make_frames(n, seed=5).to(hip_device).requires_grad_(True)
+    plan = _c3_plan(model, x)
+    f = (torch.randn((n, dims[0]), generator=torch.Generator().manual_seed(2)) * 1.5).to(hip_device)
+    g = torch.randn((n, dims[-1]), generator=torch.Generator().manual_seed(3)).to(hip_device)
+    gf = torch.full_like(f, float("nan"))
+    gp = torch.zeros(plan.grad_params_size(), device=hip_device)
+    plan.mlp_backward(f, g, gf, gp)
+    gp2 = torch.ones_like(gp)                               # accumulated into, grad_f optional
+    plan.mlp_backward(f, g, None, gp2)
+    gf2 = torch.empty_like(f)
+    plan.mlp_backward(f, g, gf2, None)                      # ... and so are the parameter gradients
+    f64 = f.double().cpu().requires_grad_(True)
+    nn64 = copy.deepcopy(model.ann_layers).double().cpu()
+    (nn64(f64) * g.double().cpu()).sum().backward()
+    s = max(1e-3, float(f64.grad.abs().max()))
+    assert float((gf.cpu().double() - f64.grad).abs().max()) <= 2e-4 * s
+    assert torch.equal(gf, gf2)
+    want = torch.cat([t.grad.reshape(-1) for lin in [m for m in nn64 if isinstance(m, torch.nn.Linear)] for t in (lin.weight, lin.bias)])
+    s = max(1e-3, float(want.abs().max()))
+    assert float((gp.cpu().double() - want).abs().max()) <= 2e-4 * s
+    assert float((gp2.cpu().double() - 1.0 - want).abs().max()) <= 2e-4 * s + 1e-6
+
+
+def test_forward_train_keeps_features_and_output_bits(hip_device):
+    w = wl.get_workload("C3")
+    model = wl.build_model(w, hip_device)
+    n = 4099
+    x = w.make_frames(n, seed=11).to(hip_device).requires_grad_(True)
+    plan = _c3_plan(model, x)
+    xd = x.detach()
+    out0, out1 = torch.empty((n, plan.out_dim), device=hip_device), torch.empty((n, plan.out_dim), device=hip_device)
+    f0, f1 = torch.empty((n, plan.feature_dim), device=hip_device), torch.empty((n, plan.feature_dim), device=hip_device)
+    plan.forward_packed(xd, out0)
+    plan.features(xd, f0)                                   # the features-only twin of the fused kernel
+    assert "molann_lane_jit<NL=0>" in plan.last_launch_info()
+    plan.forward_train(xd, out1, f1)
+    assert torch.equal(out0, out1) and torch.equal(f0, f1)
+    with torch.no_grad():
+        assert torch.equal(f0, model.preprocessing_layer(xd))
+
+
+def test_split_backward_equals_recomputing_backward(hip_device):
+    """molann_backward_f32 (features recomputed into the plan's workspace, chunked) against the saved-features pair."""
+    w = wl.get_workload("C3")
+    model = wl.build_model(w, hip_device)
+    n = 5000
+    x = w.make_frames(n, seed=12).to(hip_device).requires_grad_(True)
+    plan = _c3_plan(model, x)
+    xd = x.detach()
+    g = torch.randn((n, plan.out_dim), generator=torch.Generator().manual_seed(4)).to(hip_device)
+    gx0, gp0 = torch.empty_like(xd), torch.zeros(plan.grad_params_size(), device=hip_device)
+    plan.backward(xd, g, gx0, gp0)
+    assert "molann_mlp_bwd" in plan.last_launch_info() and "molann_lane_bwd" in plan.last_launch_info()
+    out, f = torch.empty((n, plan.out_dim), device=hip_device), torch.empty((n, plan.feature_dim), device=hip_device)
+    plan.forward_train(xd, out, f)
+    gf, gx1, gp1 = torch.empty_like(f), torch.empty_like(xd), torch.zeros_like(gp0)
+    plan.mlp_backward(f, g, gf, gp1)
+    plan.features_backward(xd, gf, gx1)
+    assert torch.equal(gx0, gx1)
+    assert float((gp0 - gp1).abs().max()) <= 1e-5 * max(1.0, float(gp1.abs().max()))   # block sums added in another order
+    side = torch.cuda.Stream(device=hip_device)             # the workspace is the plan's: another stream waits for the previous call
+    gx2, gp2 = torch.empty_like(xd), torch.zeros_like(gp0)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.backward(xd, g, gx2, gp2)
+    plan.backward(xd, g, gx0, gp0.zero_())
+    torch.cuda.synchronize()
+    assert torch.equal(gx0, gx2) and torch.equal(gx0, gx1)
