@@ -182,13 +182,20 @@ int molann_plan_grad_params_size(const molann_plan* plan);
 /* 1 if molann_backward_f32 can serve this plan (see below), else 0. */
 int molann_plan_supports_backward(const molann_plan* plan);
 
+/* How molann_backward_f32 serves this plan: 2 = one pass over x (recompute + MLP on the matrix cores + reverse mode in one
+ * kernel: nothing worth saving from the forward), 1 = two or three launches (a caller that keeps the features of its
+ * forward, molann_forward_train_f32, saves their recompute), 0 = not at all.  Builds the kernel it reports (hipRTC). */
+int molann_plan_backward_kind(molann_plan* plan);
+
 /* Gradients of molann_forward_packed_f32 (plans with an MLP) / molann_features_f32 (plans without) for the
  * same x: grad_out[N, out_dim] -> grad_x[N, n_inp, 3] (written; zeros for atoms the plan does not touch;
  * may be NULL) and grad_params (ACCUMULATED into with float atomics, so zero it first; may be NULL).
- * Nothing is saved from the forward.  Plans with an MLP run three launches per chunk of frames - the features
- * (recomputed into a workspace the plan allocates at its first backward), molann_mlp_backward_f32 and
- * molann_features_backward_f32; a caller that kept the features of its forward (molann_features_f32 +
- * molann_mlp_packed_f32 instead of the fused launch) calls those two itself and saves the recompute.
+ * Nothing is saved from the forward.  One launch (molann_plan_backward_kind 2: loaders stream x through a ring in LDS,
+ * consumers recompute the forward per frame, run the MLP's backward on the matrix cores and the analytic reverse mode
+ * of the preprocessing) plus the reduction of the per-block parameter sums; where that kernel cannot be built, plans
+ * with an MLP run three launches per chunk of frames - the features (recomputed into a workspace the plan allocates at
+ * its first backward), molann_mlp_backward_f32 and molann_features_backward_f32 - and a caller that kept the features
+ * of its forward (molann_forward_train_f32) calls those two itself and saves the recompute.
  * Available for plans served by the lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU /
  * sigmoid / identity / SiLU / LeakyReLU (kernels compiled with hipRTC at the first call), and for feature
  * plans without an MLP on large frames (one wave per frame, float atomics into the zeroed gradient row);

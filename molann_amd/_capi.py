@@ -96,6 +96,7 @@ def lib():
             "molann_plan_last_launch_info": (i32, [vp, ctypes.c_char_p, i32]),
             "molann_plan_grad_params_size": (i32, [vp]),
             "molann_plan_supports_backward": (i32, [vp]),
+            "molann_plan_backward_kind": (i32, [vp]),
             "molann_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_forward_train_f32": (i32, [vp, vp, i64, vp, vp, vp]),
             "molann_features_backward_f32": (i32, [vp, vp, vp, i64, vp, vp]),
@@ -263,6 +264,10 @@ class Plan(object):
 
     def supports_backward(self):
         return lib().molann_plan_supports_backward(self._handle) == 1
+
+    def backward_kind(self):
+        """2: `backward` is one pass over x; 1: several launches (keep the features of the forward: `forward_train`); 0: none."""
+        return lib().molann_plan_backward_kind(self._handle)
 
     def grad_params_size(self):
         return lib().molann_plan_grad_params_size(self._handle)

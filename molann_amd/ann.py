@@ -148,17 +148,20 @@ def _release_plans(desc, device):
 
 
 class _PlanFunction(torch.autograd.Function):
-    """forward = one fused launch of the plan; with an MLP it also keeps the features (24 bytes per C3 frame), so that
-    the backward is two launches - the MLP's on the matrix cores (molann_mlp_backward_f32: dL/d features and the
-    parameter gradients), the preprocessing's (molann_features_backward_f32: recomputes Kabsch and the feature table
-    per frame from x).  `params` are the Linear weights/biases in layer order (may be empty)."""
+    """forward = one fused launch of the plan; backward = molann_backward_f32: one pass over x that recomputes the forward
+    per frame (nothing but x is saved), runs the MLP's backward on the matrix cores and the analytic reverse mode of
+    the preprocessing.  Where that kernel could not be built (`backward_kind() == 1`) the forward also keeps the
+    features and the backward is two launches, molann_mlp_backward_f32 and molann_features_backward_f32.
+    `params` are the Linear weights/biases in layer order (may be empty)."""
 
     @staticmethod
     def forward(ctx, x, entry, with_mlp, *params):
         plan = entry.plan
         out = torch.empty((x.shape[0], plan.out_dim if with_mlp else plan.feature_dim), dtype=torch.float32, device=x.device)
         feat = None
-        if with_mlp:
+        if with_mlp and entry.backward_kind() != 1:
+            plan.forward_packed(x, out)
+        elif with_mlp:
             feat = torch.empty((x.shape[0], plan.feature_dim), dtype=torch.float32, device=x.device)
             try:
                 plan.forward_train(x, out, feat)
@@ -286,6 +289,12 @@ class _PlanEntry(object):
         self.plan = plan
         self.ref_key = None
         self.mlp_key = None
+        self._bwd_kind = None
+
+    def backward_kind(self):
+        if self._bwd_kind is None:
+            self._bwd_kind = self.plan.backward_kind()     # a property of the plan: asked (and built) once
+        return self._bwd_kind
 
     def invalidate(self):
         self.ref_key = self.mlp_key = None

@@ -993,17 +993,26 @@ __global__ __launch_bounds__(256) void mlp_f64_kernel(const double* __restrict__
 }
 
 // =============================================================================================
-// dst[i] += sum over rows of part[row][i]: the per-block parameter sums of molann_mlp_bwd (one writer per element)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int n, float* __restrict__ dst) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < n_rows; r += 4) {
-        s0 += part[(long)r * n + i]; s1 += part[(long)(r + 1) * n + i]; s2 += part[(long)(r + 2) * n + i]; s3 += part[(long)(r + 3) * n + i];
+// dst[i] += sum over rows of part[row][i]: the per-block parameter sums of molann_mlp_bwd (one writer per element).
+// Block = 64 elements x 16 row groups, so a thread's chain of loads is n_rows / 16 long.
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int n, float* __restrict__ dst) {
+    __shared__ float acc[16][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + x;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int r = y;
+        for (; r + 16 < n_rows; r += 32) { s0 += part[(long)r * n + i]; s1 += part[(long)(r + 16) * n + i]; }
+        if (r < n_rows) s0 += part[(long)r * n + i];
     }
-    for (; r < n_rows; ++r) s0 += part[(long)r * n + i];
-    dst[i] += (s0 + s1) + (s2 + s3);
+    acc[y][x] = s0 + s1;
+    __syncthreads();
+    if (y == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += acc[g][x];
+        dst[i] += s;
+    }
 }
 
 // frames_wave_bwd_kernel: dL/dx of frames_wave_kernel (features of large frames), one wave per frame
@@ -1543,6 +1552,9 @@ struct molann_plan {
     hipModule_t bwd_mod;
     hipFunction_t bwd_fn;      // backward of the preprocessing (molann_lane_bwd.inc), compiled at the first backward
     int bwd_state;             // 0 not tried, 1 ready, -1 unavailable
+    hipModule_t rbwd_mod;
+    hipFunction_t rbwd_fn;     // the whole backward in one pass over x (molann_bwd_ring.inc), compiled at the first backward
+    int rbwd_state, rbwd_ncons, rbwd_nload, rbwd_nslot, rbwd_lds;
     hipModule_t mbwd_mod;
     hipFunction_t mbwd_fn;     // backward of the fused family's MLP (molann_mlp_bwd.inc), compiled at the first backward
     int mbwd_state, mbwd_wpb;
@@ -1811,6 +1823,8 @@ std::string jit_preamble(const JitSpec& j);
 
 std::string jit_source(const JitSpec& j) {
     std::string s = jit_preamble(j);
+    s += "#line 1 \"molann_ring.inc\"\n";
+    s += join_chunks(k_src_molann_ring_inc);
     s += "#line 1 \"molann_lane_jit.inc\"\n";
     s += join_chunks(k_src_molann_lane_jit_inc);
     return s;
@@ -1851,8 +1865,8 @@ int mlp_bwd_rows(const std::vector<int>& dims, int act) {
     auto act_row = [&](int l) { int r = 0; for (int i = 0; i < l; ++i) r += pad4(dims[i]); return r; };
     auto z_row = [&](int l) { int r = act_row(nl); for (int i = 0; i < l; ++i) r += pad4(dims[i + 1]); return r; };
     const int z_end = act == 5 ? z_row(nl - 1) : act_row(nl);
-    auto d_row = [&](int l) { int r = z_end; for (int i = nl - 1; i > l; --i) r += pad4(dims[i + 1]); return r; };
-    int m = d_row(0) + pad4(dims[1]);
+    auto d_row = [&](int l) { return l == nl - 1 ? z_end : act_row(l + 1); };
+    int m = z_end + pad4(dims[nl]);
     for (int l = 0; l < nl; ++l) m = std::max(m, std::max(act_row(l) + 16 * b16(dims[l]), d_row(l) + 16 * b16(dims[l + 1])));
     return m;
 }
@@ -1877,6 +1891,62 @@ std::string jit_source_mlp_bwd(const JitSpecBox& b, int wpb) {
     K("N_PARAMS", (int)g);
     s += "#line 1 \"molann_mlp_bwd.inc\"\n";
     s += join_chunks(k_src_molann_mlp_bwd_inc);
+    return s;
+}
+
+// One-pass backward (molann_bwd_ring.inc): loaders + consumers around the ring of compact tiles; every consumer owns a
+// buffer that is MLP scratch, gradient tile and parameter sums in turn.  Two waves per SIMD (256 VGPRs each).
+bool bwd_ring_geometry(JitSpec& j, int n_params) {
+    const int tile = ceil_to(64 * 16 * (int)j.win.size(), 16);
+    const int rows = j.n_layers > 0 ? mlp_bwd_rows(j.dims, j.act) : 0;
+    const int cbuf = ceil_to(std::max(std::max(64 * 12 * j.n_inp, rows * 68 * 4), std::max(16, n_params * 4)), 16);
+    const int header = 256;
+    j.bpc = 1;
+    // With an MLP the consumers are bound by their SIMDs' issue cycles (matrix and vector instructions of a SIMD do not overlap:
+    // C3 takes 114 us per 1 M frames without the gradient tile whether 4 or 7 consumers work on it), the stream needs one
+    // loader, and the seventh consumer shortens the per-wave tail of the gradient tile (152 -> 145 us).
+    int c0 = j.n_layers > 0 ? 7 : 6, ld0 = j.n_layers > 0 ? 1 : 2;
+    if (const char* e = diag_env("MOLANN_DEBUG_BWD_LC")) { // experiments: "consumers,loaders"
+        int c = 0, ld = 0;
+        if (sscanf(e, "%d,%d", &c, &ld) == 2 && c >= 1 && c <= 14 && ld >= 1 && ld <= 4) { c0 = c; ld0 = ld; }
+    }
+    for (int ncons = c0; ncons >= 2; --ncons) {
+        const int nload = ncons >= 4 ? ld0 : 1;
+        const long nslot = std::min<long>(16, (163840 - header - (long)ncons * cbuf) / tile);
+        if (nslot < 2 * nload) continue;
+        j.ncons = ncons; j.nload = nload; j.nslot = (int)nslot;
+        j.depth = std::min(6, 63 / std::max(1, (int)j.win.size()));
+        j.depth = std::min(j.depth, std::max(0, j.nslot / j.nload - 1));
+        j.ring_off = header;
+        j.tile_stride = tile;
+        j.fb_off = header + j.nslot * tile;
+        j.fb_bytes = cbuf;
+        j.lds_block = j.fb_off + j.ncons * cbuf;
+        return true;
+    }
+    return false;
+}
+
+std::string jit_source_bwd_ring(const JitSpecBox& b) {
+    const JitSpec& j = b.j;
+    std::string s = jit_preamble(j);
+    char t[128];
+    auto arr = [&](const char* name, const std::vector<long>& v) {
+        s += std::string("constexpr int ") + name + "[] = {";
+        for (size_t i = 0; i < v.size(); ++i) { snprintf(t, sizeof(t), "%s%ld", i ? ", " : "", v[i]); s += t; }
+        s += "};\n";
+    };
+    std::vector<long> kp(b.kp.begin(), b.kp.end()), jp(b.jp.begin(), b.jp.end()), woff = b.woff, goff;
+    long g = 0;
+    for (int l = 0; l < j.n_layers; ++l) { goff.push_back(g); g += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1]; }
+    if (kp.empty()) { kp.push_back(1); jp.push_back(1); woff.push_back(0); goff.push_back(0); }
+    arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
+    snprintf(t, sizeof(t), "constexpr int N_PARAMS = %ld;\n", g);
+    s += t;
+    s += "#line 1 \"molann_ring.inc\"\n";
+    s += join_chunks(k_src_molann_ring_inc);
+    s += "#line 1 \"molann_bwd_ring.inc\"\n";
+    s += join_chunks(k_src_molann_bwd_ring_inc);
     return s;
 }
 
@@ -2621,6 +2691,7 @@ int molann_plan_destroy(molann_plan* p) {
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
     if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
     if (p->mbwd_mod) (void)hipModuleUnload(p->mbwd_mod);
+    if (p->rbwd_mod) (void)hipModuleUnload(p->rbwd_mod);
     if (p->feat_mod) (void)hipModuleUnload(p->feat_mod);
     if (p->train_mod) (void)hipModuleUnload(p->train_mod);
     if (p->d_bwork) (void)hipFree(p->d_bwork);
@@ -2963,6 +3034,59 @@ int ensure_features_bwd(molann_plan* p, molann_plan::LaneGeom& g) {
     return p->bwd_state == 1 ? MOLANN_OK : MOLANN_E_UNSUPPORTED;
 }
 
+// the one-pass backward of the plan (molann_bwd_ring.inc): built at the first backward; a build that does not fit the LDS or
+// needs scratch memory (register spills) leaves the two-kernel path in charge
+int ensure_ring_bwd(molann_plan* p) {
+    if (p->rbwd_state == 0 || (p->rbwd_state == 1 && p->n_grad_params > 0 && !p->d_gpart)) {
+        std::lock_guard<std::mutex> lock(*p->jit_mu);
+        if (p->rbwd_state == 0) {
+            int st = -1;
+            JitSpecBox b = *p->spec;
+            const char* off = getenv("MOLANN_NO_RING_BWD");
+            if (!(off && off[0] == '1') && p->geom[0].ok && bwd_ring_geometry(b.j, p->n_grad_params)) {
+                std::vector<char> code;
+                std::string log;
+                const int rc = jit_compile(jit_source_bwd_ring(b), code, log);
+                int scratch = 0;
+                if (rc == 0 && hipModuleLoadData(&p->rbwd_mod, code.data()) == hipSuccess &&
+                    hipModuleGetFunction(&p->rbwd_fn, p->rbwd_mod, "molann_bwd_ring") == hipSuccess &&
+                    hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p->rbwd_fn) == hipSuccess && scratch == 0) {
+                    p->rbwd_ncons = b.j.ncons; p->rbwd_nload = b.j.nload; p->rbwd_nslot = b.j.nslot; p->rbwd_lds = b.j.lds_block;
+                    st = 1;
+                } else if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann one-pass backward not used (rc=%d, scratch=%d)\n%s\n", rc, scratch, log.c_str());
+            }
+            p->rbwd_state = st;
+        }
+        if (p->rbwd_state == 1 && p->n_grad_params > 0 && !p->d_gpart) {
+            { const int er = ensure_bwd_event(p); if (er != MOLANN_OK) return er; }
+            HIP_TRY(hipMalloc((void**)&p->d_gpart, (size_t)p->num_cus * p->n_grad_params * 4));
+        }
+    }
+    return p->rbwd_state == 1 ? MOLANN_OK : MOLANN_E_UNSUPPORTED;
+}
+
+// molann_bwd_ring (+ reduce_rows_kernel); with parameter gradients the caller holds the workspace (BwdGuard)
+int launch_ring_bwd(molann_plan* p, const float* x, const float* grad_out, long n, float* grad_x, float* grad_params, hipStream_t stream) {
+    const long n_tiles = (n + 63) / 64;
+    const int grid = (int)std::max<long>(1, std::min<long>(p->num_cus, n_tiles));
+    const bool params = grad_params && p->n_grad_params > 0;
+    struct { const float* x; const float* gout; const double* ref64; const float* wnat; float* gx; float* gp; long n; } ka =
+        {x, grad_out, p->d_ref64, (const float*)p->d_wmfma, grad_x, params ? p->d_gpart : nullptr, n};
+    size_t ksz = sizeof(ka);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+    const int block = 64 * (p->rbwd_ncons + p->rbwd_nload);
+    const hipError_t le = hipModuleLaunchKernel(p->rbwd_fn, grid, 1, 1, block, 1, 1, 0, stream, nullptr, cfg);
+    if (le != hipSuccess) return (int)le;
+    if (params) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((p->n_grad_params + 63) / 64), dim3(1024), 0, stream, p->d_gpart, grid, p->n_grad_params,
+                           grad_params);
+        HIP_TRY(hipGetLastError());
+    }
+    snprintf(p->last_info, sizeof(p->last_info), "molann_bwd_ring (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d%s",
+             p->rbwd_ncons, p->rbwd_nload, p->rbwd_nslot, grid, block, p->rbwd_lds, params ? " + reduce_rows_kernel" : "");
+    return MOLANN_OK;
+}
+
 // molann_lane_bwd: grad_f -> grad_x (no workspace)
 int launch_features_bwd(molann_plan* p, const molann_plan::LaneGeom& g, const float* x, const float* grad_f, long n, float* grad_x,
                         hipStream_t stream) {
@@ -2992,7 +3116,7 @@ int launch_mlp_bwd(molann_plan* p, const float* f, const float* grad_out, long n
     const hipError_t le = hipModuleLaunchKernel(p->mbwd_fn, grid, 1, 1, 64 * p->mbwd_wpb, 1, 1, 0, stream, nullptr, cfg);
     if (le != hipSuccess) return (int)le;
     if (grad_params) {
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((p->n_grad_params + 255) / 256), dim3(256), 0, stream, p->d_gpart, grid, p->n_grad_params,
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((p->n_grad_params + 63) / 64), dim3(1024), 0, stream, p->d_gpart, grid, p->n_grad_params,
                            grad_params);
         HIP_TRY(hipGetLastError());
     }
@@ -3022,6 +3146,19 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
         return (int)hipGetLastError();
     }
     if (!p->spec || p->n_items <= 0) return MOLANN_E_UNSUPPORTED;
+    if (p->n_layers == 0 || molann_plan_supports_backward(p)) { // one pass over x when the plan's kernel could be built
+        if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
+        if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_x) & 3) || (((uintptr_t)grad_params) & 3)) return MOLANN_E_ALIGNMENT;
+        if (!grad_x && !(grad_params && p->n_layers > 0)) return MOLANN_OK;
+        const int er = ensure_ring_bwd(p);
+        if (er == MOLANN_OK) {
+            if (!(grad_params && p->n_grad_params > 0)) return launch_ring_bwd(p, x, grad_out, (long)n, grad_x, nullptr, (hipStream_t)stream);
+            BwdGuard guard(p, (hipStream_t)stream);
+            if (guard.rc != 0) return guard.rc;
+            return launch_ring_bwd(p, x, grad_out, (long)n, grad_x, grad_params, (hipStream_t)stream);
+        }
+        if (er != MOLANN_E_UNSUPPORTED) return er;
+    }
     if (p->n_layers == 0) return molann_features_backward_f32(p, x, grad_out, n, grad_x, stream);
     // plans with an MLP, nothing saved from the forward: features (recomputed) -> MLP backward -> preprocessing backward,
     // in chunks through the plan's backward workspace (allocated at the first call, like the kernels are compiled then)
@@ -3063,6 +3200,15 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
     }
     if (rc == MOLANN_OK) snprintf(p->last_info, sizeof(p->last_info), "%.80s || %.80s || %.80s", info[0], info[1], info[2]);
     return rc;
+}
+
+// how molann_backward_f32 will serve this plan: 2 one pass over x (nothing worth saving from the forward), 1 two kernels
+// (a caller that keeps the features of its forward saves their recompute), 0 not at all.  Builds the kernel it reports.
+int molann_plan_backward_kind(molann_plan* p) {
+    if (!p) return MOLANN_E_NULL;
+    if (!molann_plan_supports_backward(p)) return 0;
+    if (!p->geom[0].ok || !p->spec) return 1;
+    return ensure_ring_bwd(p) == MOLANN_OK ? 2 : 1;
 }
 
 // dL/dx of molann_features_f32 for the same x: grad_f[N, feature_dim] -> grad_x[N, n_inp, 3]
@@ -3178,7 +3324,14 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
             off += (long)jp * kp + jp;
             off = (off + 3) & ~3l;
         }
-        if (do_compile & 8) { // ... its MLP half (molann_mlp_bwd.inc)
+        if (do_compile & 16) { // ... in one pass (molann_bwd_ring.inc)
+            if (j.n_layers > 0)
+                for (int v : j.dims) if (v > 32) return MOLANN_E_UNSUPPORTED;
+            long np = 0;
+            for (int l = 0; l < j.n_layers; ++l) np += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1];
+            if (!bwd_ring_geometry(b.j, (int)np)) return MOLANN_E_UNSUPPORTED;
+            src = jit_source_bwd_ring(b);
+        } else if (do_compile & 8) { // ... its MLP half (molann_mlp_bwd.inc)
             if (j.n_layers <= 0) return MOLANN_E_STAGE;
             for (int v : j.dims) if (v > 32) return MOLANN_E_UNSUPPORTED;
             const int rows = mlp_bwd_rows(j.dims, j.act);

@@ -73,11 +73,12 @@ for trial in range(400):
         else:
             dims = [3] * 40 if feats else dims                                # too many layers
     d, keep = desc(n_inp, align, feats, uav, dims, act=rng.randint(0, 8), prec=rng.randint(0, 1))
-    for mode in (0, 1, 2):     # source only; + compile omitted here (hipRTC is third-party code); backward source
-        rc = L.molann_debug_jit(ctypes.byref(d), mode & 2, buf, 1 << 21)
+    # source only (compiling is hipRTC's, third-party code): forward, backward of the preprocessing, of the MLP, in one pass
+    for mode, name in ((0, b"molann_lane_jit"), (2, b"molann_lane_bwd"), (10, b"molann_mlp_bwd"), (18, b"molann_bwd_ring")):
+        rc = L.molann_debug_jit(ctypes.byref(d), mode, buf, 1 << 21)
         if rc > 0:
             n_ok += 1
-            assert b"molann_lane" in buf.value
+            assert name in buf.value
         else:
             n_rej += 1
     h = ctypes.c_void_p()

@@ -302,13 +302,16 @@ def test_forward_train_keeps_features_and_output_bits(hip_device):
         assert torch.equal(f0, model.preprocessing_layer(xd))
 
 
-def test_split_backward_equals_recomputing_backward(hip_device):
-    """molann_backward_f32 (features recomputed into the plan's workspace, chunked) against the saved-features pair."""
+def test_split_backward_equals_recomputing_backward(hip_device, monkeypatch):
+    """Without the one-pass kernel: molann_backward_f32 (features recomputed into the plan's workspace, chunked) against
+    the saved-features pair."""
+    monkeypatch.setenv("MOLANN_NO_RING_BWD", "1")
     w = wl.get_workload("C3")
     model = wl.build_model(w, hip_device)
     n = 5000
     x = w.make_frames(n, seed=12).to(hip_device).requires_grad_(True)
     plan = _c3_plan(model, x)
+    assert plan.backward_kind() == 1
     xd = x.detach()
     g = torch.randn((n, plan.out_dim), generator=torch.Generator().manual_seed(4)).to(hip_device)
     gx0, gp0 = torch.empty_like(xd), torch.zeros(plan.grad_params_size(), device=hip_device)
@@ -329,3 +332,43 @@ def test_split_backward_equals_recomputing_backward(hip_device):
     plan.backward(xd, g, gx0, gp0.zero_())
     torch.cuda.synchronize()
     assert torch.equal(gx0, gx2) and torch.equal(gx0, gx1)
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C3", "C2"])
+def test_one_pass_backward_against_the_two_kernel_path(cfg, hip_device, monkeypatch):
+    """molann_bwd_ring (what molann_backward_f32 launches by default) against the split path on the same inputs, and
+    its workspace protocol across streams."""
+    w = wl.get_workload(cfg)
+    n = 70001
+    x = w.make_frames(n, seed=13).to(hip_device).requires_grad_(True)
+    model = wl.build_model(w, hip_device)
+    G = torch.randn((n, w.out_dim()), generator=torch.Generator().manual_seed(5)).to(hip_device)
+    (model(x) * G).sum().backward()
+    info = model.last_launch_info() if hasattr(model, "last_launch_info") else ""
+    got = [x.grad.clone()] + [p.grad.clone() for p in model.parameters()]
+    monkeypatch.setenv("MOLANN_NO_RING_BWD", "1")
+    model2 = wl.build_model(w, hip_device)
+    model2.load_state_dict(model.state_dict())
+    x2 = x.detach().clone().requires_grad_(True)
+    (model2(x2) * G).sum().backward()
+    want = [x2.grad] + [p.grad for p in model2.parameters()]
+    for a, b in zip(got, want):
+        s = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-5 * s
+    monkeypatch.delenv("MOLANN_NO_RING_BWD")
+    if w.mlp_dims:
+        plan = model._fast_state(x)["entry"]().plan
+        assert plan.backward_kind() == 2
+        xd = x.detach()
+        gx0, gp0 = torch.empty_like(xd), torch.zeros(plan.grad_params_size(), device=hip_device)
+        plan.backward(xd, G, gx0, gp0)
+        assert "molann_bwd_ring" in plan.last_launch_info()
+        side = torch.cuda.Stream(device=hip_device)
+        gx1, gp1 = torch.empty_like(xd), torch.zeros_like(gp0)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            plan.backward(xd, G, gx1, gp1)
+        plan.backward(xd, G, gx0, gp0.zero_())
+        torch.cuda.synchronize()
+        assert torch.equal(gx0, gx1) and torch.equal(gx0, got[0])
+        assert float((gp0 - gp1).abs().max()) <= 1e-5 * max(1.0, float(gp0.abs().max()))

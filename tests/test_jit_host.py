@@ -43,6 +43,21 @@ def test_specialised_kernel_compiles(name):
     assert "molann_lane_jit" in src
 
 
+@pytest.mark.parametrize("mode,entry", [(3, "molann_lane_bwd"), (11, "molann_mlp_bwd"), (19, "molann_bwd_ring")])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C3p"])
+def test_backward_kernels_compile(name, mode, entry):
+    """The plan-specialised backward kernels (preprocessing half, MLP half, one pass) cross-compile for gfx950."""
+    w = wl.get_workload(name)
+    d, keep = _desc(w)
+    buf = ctypes.create_string_buffer(1 << 21)
+    rc = _capi.lib().molann_debug_jit(ctypes.byref(d), mode, buf, 1 << 21)
+    if mode == 11 and not w.mlp_dims:
+        assert rc == _capi.E_STAGE
+        return
+    assert rc > 1000, (rc, buf.value.decode()[:3000])
+    assert entry in buf.value.decode()
+
+
 def test_large_frames_are_not_specialised():
     d, keep = _desc(wl.get_workload("C4"))
     rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 0, None, 0)
