@@ -159,7 +159,10 @@ class _PlanFunction(torch.autograd.Function):
         plan = entry.plan
         out = torch.empty((x.shape[0], plan.out_dim if with_mlp else plan.feature_dim), dtype=torch.float32, device=x.device)
         feat = None
-        if with_mlp and entry.backward_kind() != 1:
+        # What the backward will need is known here.  Gradients for x: one pass over x does everything (backward_kind 2),
+        # nothing to keep.  Parameters only (x is data): the MLP's backward alone, on the features this forward keeps
+        # (C3: 63 us per 1 M frames instead of 104 for the pass over x).
+        if with_mlp and entry.backward_kind() != 1 and ctx.needs_input_grad[0]:
             plan.forward_packed(x, out)
         elif with_mlp:
             feat = torch.empty((x.shape[0], plan.feature_dim), dtype=torch.float32, device=x.device)

@@ -3044,16 +3044,26 @@ int ensure_ring_bwd(molann_plan* p) {
             JitSpecBox b = *p->spec;
             const char* off = getenv("MOLANN_NO_RING_BWD");
             if (!(off && off[0] == '1') && p->geom[0].ok && bwd_ring_geometry(b.j, p->n_grad_params)) {
-                std::vector<char> code;
-                std::string log;
-                const int rc = jit_compile(jit_source_bwd_ring(b), code, log);
-                int scratch = 0;
-                if (rc == 0 && hipModuleLoadData(&p->rbwd_mod, code.data()) == hipSuccess &&
-                    hipModuleGetFunction(&p->rbwd_fn, p->rbwd_mod, "molann_bwd_ring") == hipSuccess &&
-                    hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p->rbwd_fn) == hipSuccess && scratch == 0) {
-                    p->rbwd_ncons = b.j.ncons; p->rbwd_nload = b.j.nload; p->rbwd_nslot = b.j.nslot; p->rbwd_lds = b.j.lds_block;
-                    st = 1;
-                } else if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann one-pass backward not used (rc=%d, scratch=%d)\n%s\n", rc, scratch, log.c_str());
+                // The kernel lives at the edge of its 256 registers.  Without SLP vectorisation first (C3: 2267 vector instructions and
+                // no scratch, against 2564 + 16 spilled registers with it); the default for the plans that spill without it.
+                const std::string src = jit_source_bwd_ring(b);
+                for (int attempt = 0; attempt < 2 && st != 1; ++attempt) {
+                    std::vector<char> code;
+                    std::string log;
+                    const int rc = jit_compile(src, code, log, attempt == 0 ? "-fno-slp-vectorize" : nullptr);
+                    int scratch = -1;
+                    hipModule_t mod = nullptr;
+                    hipFunction_t fn = nullptr;
+                    if (rc == 0 && hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "molann_bwd_ring") == hipSuccess &&
+                        hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess && scratch == 0) {
+                        p->rbwd_mod = mod; p->rbwd_fn = fn;
+                        p->rbwd_ncons = b.j.ncons; p->rbwd_nload = b.j.nload; p->rbwd_nslot = b.j.nslot; p->rbwd_lds = b.j.lds_block;
+                        st = 1;
+                    } else {
+                        if (mod) (void)hipModuleUnload(mod);
+                        if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann one-pass backward, build %d not used (rc=%d, scratch=%d)\n%s\n", attempt, rc, scratch, log.c_str());
+                    }
+                }
             }
             p->rbwd_state = st;
         }
@@ -3070,8 +3080,8 @@ int launch_ring_bwd(molann_plan* p, const float* x, const float* grad_out, long 
     const long n_tiles = (n + 63) / 64;
     const int grid = (int)std::max<long>(1, std::min<long>(p->num_cus, n_tiles));
     const bool params = grad_params && p->n_grad_params > 0;
-    struct { const float* x; const float* gout; const double* ref64; const float* wnat; float* gx; float* gp; long n; } ka =
-        {x, grad_out, p->d_ref64, (const float*)p->d_wmfma, grad_x, params ? p->d_gpart : nullptr, n};
+    struct { const float* x; const float* gout; const double* ref64; const float* ref32; const float* wnat; float* gx; float* gp; long n; } ka =
+        {x, grad_out, p->d_ref64, p->d_ref, (const float*)p->d_wmfma, grad_x, params ? p->d_gpart : nullptr, n};
     size_t ksz = sizeof(ka);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
     const int block = 64 * (p->rbwd_ncons + p->rbwd_nload);

@@ -484,40 +484,47 @@ MOLANN_HD float act_derivative(int act, float z, float h) {
 // Backward of kabsch_rotation: given H, the rotation R it produced and G_R = dL/dR, returns G_H = dL/dH.
 // With S = R^T H (symmetric at the optimum) a perturbation dH turns R by dR = R [w]x where
 // (tr(S) I - S) w = vee(R^T dH - dH^T R); hence G_H = R [n]x, n = (tr(S) I - S)^-1 vee(M - M^T), M = R^T G_R.
-// ([v]x = cross-product matrix of v.)  fp64: 3x3 products and one 3x3 symmetric solve.
-MOLANN_HD void kabsch_rotation_backward(const double (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
-    double S[9], M[9];
+// ([v]x = cross-product matrix of v.)  3x3 products and one 3x3 symmetric solve in T: double, or float where the forward's
+// Kabsch is float as well (plans whose items are all invariant under rigid motion).
+template <typename T>
+MOLANN_HD void kabsch_rotation_backward_t(const T (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
+    T S[9], M[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            double s = 0.0, m = 0.0;
+            T s = (T)0, m = (T)0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { s = fma((double)R[3 * k + a], H[3 * k + b], s); m = fma((double)R[3 * k + a], (double)GR[3 * k + b], m); }
+            for (int k = 0; k < 3; ++k) { s = tfma((T)R[3 * k + a], H[3 * k + b], s); m = tfma((T)R[3 * k + a], (T)GR[3 * k + b], m); }
             S[3 * a + b] = s;
             M[3 * a + b] = m;
         }
-    const double s01 = 0.5 * (S[1] + S[3]), s02 = 0.5 * (S[2] + S[6]), s12 = 0.5 * (S[5] + S[7]);
-    const double tr = S[0] + S[4] + S[8];
+    const T s01 = (T)0.5 * (S[1] + S[3]), s02 = (T)0.5 * (S[2] + S[6]), s12 = (T)0.5 * (S[5] + S[7]);
+    const T tr = S[0] + S[4] + S[8];
     // B = tr I - S  (symmetric)
-    const double b00 = tr - S[0], b11 = tr - S[4], b22 = tr - S[8], b01 = -s01, b02 = -s02, b12 = -s12;
-    const double m0 = M[7] - M[5], m1 = M[2] - M[6], m2 = M[3] - M[1]; // vee(M - M^T)
+    const T b00 = tr - S[0], b11 = tr - S[4], b22 = tr - S[8], b01 = -s01, b02 = -s02, b12 = -s12;
+    const T m0 = M[7] - M[5], m1 = M[2] - M[6], m2 = M[3] - M[1]; // vee(M - M^T)
     // n = B^-1 m by the adjugate
-    const double c00 = b11 * b22 - b12 * b12, c01 = b02 * b12 - b01 * b22, c02 = b01 * b12 - b02 * b11;
-    const double c11 = b00 * b22 - b02 * b02, c12 = b01 * b02 - b00 * b12, c22 = b00 * b11 - b01 * b01;
-    const double det = b00 * c00 + b01 * c01 + b02 * c02;
-    const double inv = (det > 1e-300 || det < -1e-300) ? 1.0 / det : 0.0; // ill-defined rotation: no gradient through R
-    const double n0 = (c00 * m0 + c01 * m1 + c02 * m2) * inv;
-    const double n1 = (c01 * m0 + c11 * m1 + c12 * m2) * inv;
-    const double n2 = (c02 * m0 + c12 * m1 + c22 * m2) * inv;
+    const T c00 = b11 * b22 - b12 * b12, c01 = b02 * b12 - b01 * b22, c02 = b01 * b12 - b02 * b11;
+    const T c11 = b00 * b22 - b02 * b02, c12 = b01 * b02 - b00 * b12, c22 = b00 * b11 - b01 * b01;
+    const T det = b00 * c00 + b01 * c01 + b02 * c02;
+    constexpr T tiny = sizeof(T) == 8 ? (T)1e-300 : (T)1e-30;
+    const T inv = (det > tiny || det < -tiny) ? (T)1 / det : (T)0; // ill-defined rotation: no gradient through R
+    const T n0 = (c00 * m0 + c01 * m1 + c02 * m2) * inv;
+    const T n1 = (c01 * m0 + c11 * m1 + c12 * m2) * inv;
+    const T n2 = (c02 * m0 + c12 * m1 + c22 * m2) * inv;
     // G_H = R [n]x ,  [n]x = [[0,-n2,n1],[n2,0,-n0],[-n1,n0,0]]
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const double r0 = R[3 * a], r1 = R[3 * a + 1], r2 = R[3 * a + 2];
+        const T r0 = R[3 * a], r1 = R[3 * a + 1], r2 = R[3 * a + 2];
         GH[3 * a + 0] = (float)(r1 * n2 - r2 * n1);
         GH[3 * a + 1] = (float)(r2 * n0 - r0 * n2);
         GH[3 * a + 2] = (float)(r0 * n1 - r1 * n0);
     }
+}
+
+MOLANN_HD void kabsch_rotation_backward(const double (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
+    kabsch_rotation_backward_t<double>(H, R, GR, GH);
 }
 
 } // namespace molann
