@@ -3323,6 +3323,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
     jit_geometry(j, g, col, std::max(1, d->n_layers > 0 ? ceil_to(col, 4) : col));
     if (!g.ok || 3 * d->n_inp < 4) return MOLANN_E_UNSUPPORTED;
     j.waves_per_eu = 2;
+    j.save_feat = (do_compile & 32) != 0 && j.n_layers > 0;   // the feature-keeping twin of the fused forward
     std::string src = jit_source(j);
     if (do_compile & 2) { // the backward kernel of the same plan
         JitSpecBox b;

@@ -32,6 +32,9 @@ def timeit(fn, reps=10):
 s = 1e6 / n
 print("per 1M frames (n = %d)" % n)
 print("features (twin of the fused kernel) : %7.1f us   %s" % (timeit(lambda: plan.features(x.detach(), f)) * s, plan.last_launch_info()[:60]))
+o2 = torch.empty((n, plan.out_dim), device=dev)
+print("forward_packed                      : %7.1f us" % (timeit(lambda: plan.forward_packed(x.detach(), o2)) * s))
+print("forward_train (keeps the features)  : %7.1f us" % (timeit(lambda: plan.forward_train(x.detach(), o2, f)) * s))
 print("mlp_packed                          : %7.1f us" % (timeit(lambda: plan.mlp_packed(f, g.new_empty((n, plan.out_dim)))) * s))
 print("mlp_backward  grad_f + grad_params  : %7.1f us" % (timeit(lambda: plan.mlp_backward(f, g, gf, gp)) * s))
 print("mlp_backward  grad_params only      : %7.1f us" % (timeit(lambda: plan.mlp_backward(f, g, None, gp)) * s))
