@@ -1560,6 +1560,10 @@ struct molann_plan {
     int mbwd_state, mbwd_wpb;
     // features-only twin of a forward kernel that has the MLP fused in (what molann_features_f32 and the backward's
     // recompute launch on such a plan), compiled at the first use
+    struct JitSpecBox* align_spec;  // AlignmentLayer.forward as alignment + one position item per atom through the specialised kernel
+    hipModule_t align_mod;
+    hipFunction_t align_fn;    // ... compiled at the first molann_align_f32
+    int align_state;
     hipModule_t train_mod;
     hipFunction_t train_fn;    // the fused forward kernel that also writes the features (molann_forward_train_f32), same geometry
     int train_state;
@@ -2657,6 +2661,25 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         p->jit_only = false;
         if (!p->geom[0].ok) p->family = 1; // features from the wave-per-frame kernel
     }
+    // ---- AlignmentLayer.forward through the specialised kernel: the aligned frame is the feature row of one position item per
+    // atom, so molann_align_f32 is the loader / consumer kernel too (built at its first call).  Small frames only.
+    if (d->n_align > 0 && d->n_inp <= JIT_MAX_SLOTS && 3 * d->n_inp <= LANE_MAX_COLS && 3 * d->n_inp >= 4 && rtc_api()->ok &&
+        !(nojit && nojit[0] == '1')) {
+        JitSpec j;
+        std::vector<int> seen(d->n_inp, 0);
+        bool distinct = true;
+        for (int i = 0; i < d->n_align; ++i) { distinct = distinct && !seen[d->align_idx[i]]; seen[d->align_idx[i]] = 1; j.slots.push_back(d->align_idx[i]); }
+        for (int a = 0; a < d->n_inp; ++a) if (!seen[a]) j.slots.push_back(a);
+        if (distinct) {
+            for (int u = 0; u < d->n_inp; ++u) { ItemDev it = {IT_POSITION, 3 * j.slots[u], {u, u, u, u}, {0, 0}}; j.items.push_back(it); }
+            j.n_inp = d->n_inp; j.n_align = d->n_align; j.act = 0; j.d_feat = 3 * d->n_inp; j.n_layers = 0; j.out_cols = 3 * d->n_inp;
+            j.win = compact_windows(j.slots, d->n_inp);
+            molann_plan::LaneGeom g;
+            memset(&g, 0, sizeof(g));
+            jit_geometry(j, g, j.d_feat, j.d_feat);
+            if (g.ok && (p->align_spec = new (std::nothrow) JitSpecBox())) p->align_spec->j = j;
+        }
+    }
     // ---- plan-specialised wide bf16 MLP ----------------------------------------------------------------
     snprintf(p->chain_note, sizeof(p->chain_note), "chain: not applicable");
     if (chain_fb > 0 && !(nojit && nojit[0] == '1')) {
@@ -2694,6 +2717,8 @@ int molann_plan_destroy(molann_plan* p) {
     if (p->rbwd_mod) (void)hipModuleUnload(p->rbwd_mod);
     if (p->feat_mod) (void)hipModuleUnload(p->feat_mod);
     if (p->train_mod) (void)hipModuleUnload(p->train_mod);
+    if (p->align_mod) (void)hipModuleUnload(p->align_mod);
+    delete p->align_spec;
     if (p->d_bwork) (void)hipFree(p->d_bwork);
     if (p->d_gpart) (void)hipFree(p->d_gpart);
     if (p->ev_bwork) (void)hipEventDestroy(p->ev_bwork);
@@ -2792,6 +2817,35 @@ int molann_align_f32(const molann_plan* cp, const float* x, int64_t n, float* ou
     if (p->n_align <= 0) return MOLANN_E_STAGE;
     const int c = check_io(x, out_xyz, n);
     if (c != MOLANN_OK || n == 0) return c;
+    if (p->align_spec && p->align_state >= 0 && (debug_env().ablate & ~(32 | 512)) == 0) {
+        if (p->align_state == 0) {
+            std::lock_guard<std::mutex> lock(*p->jit_mu);
+            if (p->align_state == 0) {
+                std::vector<char> code;
+                std::string log;
+                int st = -1;
+                if (jit_compile(jit_source(p->align_spec->j), code, log, "-fno-slp-vectorize") == 0 && hipModuleLoadData(&p->align_mod, code.data()) == hipSuccess &&
+                    hipModuleGetFunction(&p->align_fn, p->align_mod, "molann_lane_jit") == hipSuccess)
+                    st = 1;
+                else if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann alignment jit failed\n%s\n", log.c_str());
+                p->align_state = st;
+            }
+        }
+        if (p->align_state == 1) {
+            const JitSpec& j = p->align_spec->j;
+            const long n_tiles = (n + 63) / 64;
+            const int grid = grid_for(p, n_tiles, 1, j.bpc);
+            struct { const float* x; float* out; const double* ref64; const float* wfrag; long n; int out_vec4, pad_;
+                     unsigned long long* stamps; const float* ref32; float* feat; } ka = {x, out_xyz, p->d_ref64, nullptr, (long)n, 0, 0, nullptr, p->d_ref, nullptr};
+            size_t ksz = sizeof(ka);
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+            const int block = 64 * (j.ncons + j.nload);
+            const hipError_t le = hipModuleLaunchKernel(p->align_fn, grid, 1, 1, block, 1, 1, 0, (hipStream_t)stream, nullptr, cfg);
+            snprintf(p->last_info, sizeof(p->last_info), "molann_lane_jit<align_out> (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d",
+                     j.ncons, j.nload, j.nslot, grid, block, j.lds_block);
+            return (int)le;
+        }
+    }
     return launch_pre(p, x, n, out_xyz, 1, false, (hipStream_t)stream);
 }
 
