@@ -20,6 +20,11 @@
  *     workspace, a side stream and events: its forward calls are serialised by the library itself (a
  *     host mutex around the enqueue; a caller on another stream first waits for the event recorded
  *     behind the previous call), so they are safe from any stream or thread but do not overlap.
+ *     The same protocol covers the backward's plan-owned workspaces (per-block parameter sums; the recomputed
+ *     features of the three-launch path).  The FIRST call of an entry point whose kernel is built lazily (the
+ *     backward kernels, molann_forward_train_f32, molann_features_f32 on a plan with a fused MLP, molann_align_f32
+ *     on small frames) compiles it with hipRTC and may allocate its workspace: make that call outside a graph
+ *     capture (molann_plan_backward_kind builds the backward ahead of time).
  *   - x is [n_frames, n_inp, 3] fp32, contiguous, frame-major / atom-major / xyz-minor (the layout of
  *     the tensor the reference's forward receives, ann.py:170).  Any 4-byte aligned pointer works;
  *     16-byte aligned pointers take the wide-load path.
