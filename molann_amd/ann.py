@@ -586,6 +586,19 @@ class MolANN(_PlanOwner, torch.nn.Module):
                                 mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
         return script.ScriptPlan(desc, ref_x=al.ref_x if al is not None else None, linears=linears)
 
+    def plan_for(self, x):
+        """The C-ABI plan (ctypes, `_capi.Plan`) of this model on x's device with `ref_x` and the Linear parameters packed:
+        what tools/ and the tests of single entry points work on.  None if the model is not served by one fused plan."""
+        st = self._fast_state(x)
+        if not st["fused"]:
+            return None
+        entry = st["entry"]()
+        with torch.cuda.device(x.device):
+            if st["al"] is not None:
+                entry.sync_ref(_device_buffer(st["al"].ref_x, x))
+            entry.sync_mlp(st["linears"])
+        return entry.plan
+
     def last_launch_info(self):
         """Name + geometry of the kernels the last forward launched (bench / profiles / tests)."""
         st = self.__dict__.get("_fast")
@@ -679,7 +692,18 @@ class MolANN(_PlanOwner, torch.nn.Module):
                 raise RuntimeError("ann_layers must be float32 on %s (got %s on %s)" % (x.device, w0.dtype, w0.device))
             if st.get("fused_bwd") is None:           # asked once: the answer is a property of the plan
                 with torch.cuda.device(x.device):
-                    st["fused_bwd"] = bool(st["entry"]().plan.supports_backward())
+                    if st["op"] is not None:
+                        st["fused_bwd"] = bool(torch.ops.molann.supports_backward(
+                            x, st["desc"], _device_buffer(al.ref_x, x) if al is not None else st["no_ref"]))
+                    else:
+                        st["fused_bwd"] = bool(st["entry"]().plan.supports_backward())
+            if st["fused_bwd"] and st["op"] is not None:
+                # the dispatcher operator's autograd node (csrc/molann_torch.cpp): the same kernels and the same choice between the
+                # one-pass backward and the MLP's backward on kept features when x is data.  A training step costs ~100 us of
+                # host time through it against ~195 through the Python autograd.Function below (tools/host_overhead.py)
+                lins = st["linears"]
+                return st["op"](x, st["desc"], _device_buffer(al.ref_x, x) if al is not None else st["no_ref"],
+                                [lin.weight for lin in lins], [lin.bias for lin in lins])
             if st["fused_bwd"]:
                 entry = st["entry"]()
                 with torch.cuda.device(x.device):

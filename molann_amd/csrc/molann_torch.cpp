@@ -330,6 +330,60 @@ std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int
     return {gx, gp};
 }
 
+// The fused forward that also keeps the features: {out, features} - or {out, empty} where the plan has no such twin of its
+// kernel (molann_plan_backward_kind != 1 ... != 2 plans recompute in molann_backward_f32).  float32 fused plans.
+std::vector<at::Tensor> run_train_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                                      std::vector<at::Tensor> biases) {
+    check_x(x_in, desc);
+    TORCH_CHECK(desc[1] == KIND_FORWARD && x_in.scalar_type() == at::kFloat, "molann::run_train: float32 forward plans only");
+    const at::Tensor x = x_in.contiguous();
+    const c10::DeviceGuard guard(x.device());
+    auto e = entry_for(desc, x, ref_x);
+    const int64_t n = x.size(0);
+    at::Tensor out = at::empty({n, e->out_dim}, x.options());
+    at::Tensor feat = at::empty({n, e->feature_dim}, x.options());
+    if (n == 0) return {out, feat};
+    hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    sync_live(*e, x, ref_x, weights, biases, stream);
+    const int rc = molann_forward_train_f32(e->plan, x.data_ptr<float>(), n, out.data_ptr<float>(), feat.data_ptr<float>(), stream);
+    if (rc == MOLANN_E_UNSUPPORTED) {
+        check(molann_forward_packed_f32(e->plan, x.data_ptr<float>(), n, out.data_ptr<float>(), stream), "molann_forward_packed_f32");
+        return {out, at::empty({0}, x.options())};
+    }
+    check(rc, "molann_forward_train_f32");
+    return {out, feat};
+}
+
+// flat parameter gradients (dW_l, db_l per layer) of the MLP alone, from the features run_train kept
+at::Tensor run_backward_mlp_hip(const at::Tensor& feat, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                                std::vector<at::Tensor> biases, const at::Tensor& grad_out) {
+    TORCH_CHECK(desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD && feat.dim() == 2 && feat.scalar_type() == at::kFloat, "molann::run_backward_mlp: bad arguments");
+    const at::Tensor f = feat.contiguous();
+    const c10::DeviceGuard guard(f.device());
+    auto e = entry_for(desc, f, ref_x);
+    const int64_t n = f.size(0);
+    TORCH_CHECK(f.size(1) == e->feature_dim, "molann::run_backward_mlp: features are [*, ", e->feature_dim, "], got ", f.sizes());
+    at::Tensor g = grad_out.to(at::kFloat).reshape({n, e->out_dim}).contiguous();
+    at::Tensor gp = at::zeros({molann_plan_grad_params_size(e->plan)}, f.options());
+    if (n == 0) return gp;
+    hipStream_t stream = c10::hip::getCurrentHIPStream(f.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    // (the parameters were packed by the forward of this step; a step that changed them in between repacks here)
+    sync_live(*e, f, ref_x, weights, biases, stream);
+    check(molann_mlp_backward_f32(e->plan, f.data_ptr<float>(), g.data_ptr<float>(), n, nullptr, gp.data_ptr<float>(), stream),
+          "molann_mlp_backward_f32");
+    return gp;
+}
+
+// 1 if the plan of `desc` on x's device has backward kernels (molann_plan_supports_backward), else 0
+int64_t supports_backward(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x) {
+    check_x(x, desc);
+    TORCH_CHECK(x.is_cuda(), "molann::supports_backward: x must be a device tensor");
+    const c10::DeviceGuard guard(x.device());
+    return molann_plan_supports_backward(entry_for(desc, x, ref_x)->plan) == 1 ? 1 : 0;
+}
+
 // name + geometry of the kernels the plan of (desc, device) launched last ("" before its first launch)
 std::string launch_info(std::vector<int64_t> desc, int64_t device) {
     std::shared_ptr<Entry> e;
@@ -406,6 +460,24 @@ std::vector<at::Tensor> call_run_backward(const at::Tensor& x, const std::vector
     return op.call(x, desc, ref_x, weights, biases, grad_out, need_x, need_params);
 }
 
+std::vector<at::Tensor> call_run_train(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                                       const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("molann::run_train", "")
+                         .typed<std::vector<at::Tensor>(const at::Tensor&, std::vector<int64_t>, const at::Tensor&, std::vector<at::Tensor>,
+                                                        std::vector<at::Tensor>)>();
+    return op.call(x, desc, ref_x, weights, biases);
+}
+
+at::Tensor call_run_backward_mlp(const at::Tensor& feat, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                                 const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases, const at::Tensor& grad_out) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("molann::run_backward_mlp", "")
+                         .typed<at::Tensor(const at::Tensor&, std::vector<int64_t>, const at::Tensor&, std::vector<at::Tensor>, std::vector<at::Tensor>,
+                                           const at::Tensor&)>();
+    return op.call(feat, desc, ref_x, weights, biases, grad_out);
+}
+
 // forward = one launch of the plan, nothing but the inputs saved; backward = molann_backward_f32, which
 // recomputes the forward per frame (first-order only: the backward is not itself differentiable)
 struct RunFunction : public torch::autograd::Function<RunFunction> {
@@ -413,13 +485,25 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, std::vector<int64_t> desc,
                               const at::Tensor& ref_x, at::TensorList weights, at::TensorList biases) {
         at::AutoDispatchBelowADInplaceOrView below;
-        at::Tensor out = call_run(x, desc, ref_x, weights.vec(), biases.vec());
+        // What the backward will need is known here.  Gradients for x: molann_backward_f32 is one pass over x that
+        // recomputes everything, nothing to keep.  Parameters only (x is data): the MLP's backward alone, on the features
+        // this forward keeps - no second pass over x.
+        at::Tensor out, feat;
+        if (desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD && !x.requires_grad() && x.scalar_type() == at::kFloat && x.is_cuda()) {
+            std::vector<at::Tensor> r = call_run_train(x, desc, ref_x, weights.vec(), biases.vec());
+            out = r[0];
+            if (r[1].numel() > 0 || x.size(0) == 0) feat = r[1];
+        } else {
+            out = call_run(x, desc, ref_x, weights.vec(), biases.vec());
+        }
         std::vector<at::Tensor> saved = {x, ref_x};
         for (auto& w : weights) saved.push_back(w);
         for (auto& b : biases) saved.push_back(b);
+        if (feat.defined()) saved.push_back(feat);
         ctx->save_for_backward(saved);
         ctx->saved_data["desc"] = desc;
         ctx->saved_data["n_layers"] = (int64_t)weights.size();
+        ctx->saved_data["kept_features"] = feat.defined();
         return out;
     }
 
@@ -443,7 +527,11 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
         std::vector<at::Tensor> g;
         {
             at::AutoDispatchBelowADInplaceOrView below;
-            g = call_run_backward(x, desc, ref_x, weights, biases, grad_outputs[0], need_x, need_p);
+            if (ctx->saved_data["kept_features"].toBool() && !need_x) {
+                g = {at::Tensor(), need_p ? call_run_backward_mlp(saved[2 + 2 * nl], desc, ref_x, weights, biases, grad_outputs[0]) : at::Tensor()};
+            } else {
+                g = call_run_backward(x, desc, ref_x, weights, biases, grad_outputs[0], need_x, need_p);
+            }
         }
         torch::autograd::variable_list out(3 + 2 * nl);
         if (need_x) out[0] = g[0];
@@ -527,6 +615,9 @@ TORCH_LIBRARY(molann, m) {
     m.def("run(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor");
     m.def("run_backward(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, bool need_x, "
           "bool need_params) -> Tensor[]");
+    m.def("run_train(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor[]");
+    m.def("run_backward_mlp(Tensor feat, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out) -> Tensor");
+    m.def("supports_backward(Tensor x, int[] desc, Tensor ref_x) -> int", supports_backward);
     m.def("launch_info(int[] desc, int device) -> str", launch_info);
     m.def("invalidate(int[] desc, int device) -> ()", invalidate);
     m.def("release(int[] desc, int device) -> ()", release);
@@ -537,6 +628,8 @@ TORCH_LIBRARY(molann, m) {
 TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP device "cuda"
     m.impl("run", run_hip);
     m.impl("run_backward", run_backward_hip);
+    m.impl("run_train", run_train_hip);
+    m.impl("run_backward_mlp", run_backward_mlp_hip);
 }
 
 TORCH_LIBRARY_IMPL(molann, Autograd, m) { m.impl("run", run_autograd); }

@@ -243,11 +243,8 @@ def test_wide_mlp_trains_through_hip_features(act, hip_device):
 # ---- the halves of the backward through the C ABI (molann_forward_train_f32, molann_mlp_backward_f32,
 # molann_features_backward_f32) -------------------------------------------------------------------------------------------
 def _c3_plan(model, x):
-    """The ctypes plan of a MolANN (weights packed by a first forward + backward)."""
-    model(x).sum().backward()
-    for p in model.parameters():
-        p.grad = None
-    return model._fast_state(x)["entry"]().plan
+    """The ctypes plan of a MolANN, weights packed."""
+    return model.plan_for(x)
 
 
 @pytest.mark.parametrize("dims,act", [([6, 32, 8], torch.nn.Tanh), ([6, 32, 32, 3], torch.nn.Tanh), ([6, 17, 5, 9, 2], torch.nn.Sigmoid),
@@ -357,7 +354,7 @@ def test_one_pass_backward_against_the_two_kernel_path(cfg, hip_device, monkeypa
         assert float((a - b).abs().max()) <= 2e-5 * s
     monkeypatch.delenv("MOLANN_NO_RING_BWD")
     if w.mlp_dims:
-        plan = model._fast_state(x)["entry"]().plan
+        plan = model.plan_for(x)
         assert plan.backward_kind() == 2
         xd = x.detach()
         gx0, gp0 = torch.empty_like(xd), torch.zeros(plan.grad_params_size(), device=hip_device)

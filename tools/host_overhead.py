@@ -19,6 +19,19 @@ for need_x in (True, False):
     for _ in range(200): step(need_x)
     torch.cuda.synchronize()
     print("need_x=%s: %.1f us per step (host-bound batch of 256 frames)" % (need_x, (time.perf_counter() - t0) / 200 * 1e6))
+import warnings
+warnings.simplefilter("ignore")
+scripted = torch.jit.script(model)
+def step_s(need_x):
+    x = x0.detach().requires_grad_(need_x)
+    scripted(x).backward(G)
+for need_x in (True, False):
+    for _ in range(20): step_s(need_x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200): step_s(need_x)
+    torch.cuda.synchronize()
+    print("scripted (C++ autograd node) need_x=%s: %.1f us per step" % (need_x, (time.perf_counter() - t0) / 200 * 1e6))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(200): step(False)

@@ -12,7 +12,7 @@ x = w.make_frames(n, device=dev, seed=1).requires_grad_(True)
 model(x).sum().backward()
 def find_plan(m):
     if hasattr(m, "_fast_state"):
-        return m._fast_state(x)["entry"]().plan
+        return m.plan_for(x)
     for mod in m.modules():
         for e in getattr(mod, "_plans", lambda: {})().values():
             if hasattr(e, "plan") and e.plan.supports_backward():

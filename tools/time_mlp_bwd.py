@@ -13,8 +13,7 @@ x = w.make_frames(n, device=dev, seed=1)
 x.requires_grad_(True)
 out = model(x)                      # builds the plan, packs the weights
 out.sum().backward()
-st = model._fast_state(x)
-plan = st["entry"]().plan
+plan = model.plan_for(x)
 f = torch.empty((n, plan.feature_dim), device=dev)
 plan.features(x.detach(), f)
 g = torch.randn((n, plan.out_dim), device=dev)
