@@ -171,6 +171,12 @@ int molann_plan_update_ref_f64(molann_plan* plan, const double* ref_x, molann_st
 int molann_align_f64(const molann_plan* plan, const double* x, int64_t n_frames, double* out_xyz, molann_stream_t stream);
 /* PreprocessingANN.forward / FeatureLayer.forward ann.py:454-474, 553-565 in float64: out[N, feature_dim]. */
 int molann_features_f64(const molann_plan* plan, const double* x, int64_t n_frames, double* out, molann_stream_t stream);
+/* dL/dx of molann_features_f64 for the same x (the reference differentiates its float64 forward with autograd too):
+ * grad_f[N, feature_dim] -> grad_x[N, n_inp, 3], doubles, any frame size.  The MLP of a float64 model is differentiated by
+ * the caller (torch autograd over its own Linear modules). */
+int molann_features_backward_f64(const molann_plan* plan, const double* x, const double* grad_f, int64_t n_frames, double* grad_x,
+                                 molann_stream_t stream);
+
 /* ann_layers ann.py:60-65 in float64 on features f[N, layer_dims[0]]: W, b HOST arrays of n_layers device pointers. */
 int molann_mlp_f64(const molann_plan* plan, const double* f, int64_t n_frames, const double* const* W, const double* const* b,
                    double* out, molann_stream_t stream);

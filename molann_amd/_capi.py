@@ -99,6 +99,7 @@ def lib():
             "molann_plan_backward_kind": (i32, [vp]),
             "molann_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_forward_train_f32": (i32, [vp, vp, i64, vp, vp, vp]),
+            "molann_features_backward_f64": (i32, [vp, vp, vp, i64, vp, vp]),
             "molann_features_backward_f32": (i32, [vp, vp, vp, i64, vp, vp]),
             "molann_mlp_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_debug_read_stamps": (i32, [vp]),
@@ -229,6 +230,12 @@ class Plan(object):
         _check(lib().molann_forward_f64(self._handle, x.data_ptr(), x.shape[0], W, B, work.data_ptr(), out.data_ptr(),
                                         self._stream()), "molann_forward_f64")
         return out
+
+    def features_backward_f64(self, x, grad_f, grad_x):
+        code = _lib.molann_features_backward_f64(self._handle, x.data_ptr(), grad_f.data_ptr(), x.shape[0], grad_x.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_features_backward_f64")
 
     def mlp_f64(self, f, weights, biases, out):
         n = len(weights)

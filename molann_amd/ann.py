@@ -11,7 +11,8 @@ in ``libmolann_hip.so`` (see ``include/molann_hip.h``).
 
 There is no CPU or composite-PyTorch fallback: a forward on anything but a float32 or float64 tensor that
 lives on a HIP device raises.  float64 (`model.double()(x.double())`, which the reference supports because its
-modules follow x.dtype) runs the `molann_*_f64` kernels: forward only.  Gradients (w.r.t. x and the Linear parameters) come from hand-written backward
+modules follow x.dtype) runs the `molann_*_f64` kernels; under grad mode its features are differentiated by
+`molann_features_backward_f64` and its MLP runs as the torch module it is.  float32 gradients (w.r.t. x and the Linear parameters) come from hand-written backward
 kernels: fused with the MLP for the plans the lane-per-frame kernel serves (22-atom class, MLP widths <= 32),
 features only on large frames (one wave per frame).  With an MLP outside the fused kernel (wider, ELU / GELU /
 Softplus, or any MLP on large frames) a forward under grad mode takes features and their gradient from the
@@ -124,15 +125,12 @@ def _wants_grad(x, grad_sources=()):
 
 
 def _device_input(x, grad_sources=(), backward_ok=False):
-    """The tensor the kernels read: float32 (or float64: forward only), on a HIP device, contiguous.  Everything else raises."""
+    """The tensor the kernels read: float32 or float64, on a HIP device, contiguous.  Everything else raises."""
     if not x.is_cuda:
         raise RuntimeError("molann_amd runs on the MI355X only: got a %s tensor (no CPU path; move x and the "
                            "module to a HIP device)" % x.device.type)
     if x.dtype not in (torch.float32, torch.float64):
         raise TypeError("molann_amd kernels are float32 / float64; got %s" % x.dtype)
-    if x.dtype == torch.float64 and _wants_grad(x, grad_sources):
-        raise NotImplementedError("the float64 kernels are forward only: call the float64 model under torch.no_grad() "
-                                  "(gradients come from the float32 kernels)")
     if not backward_ok and _wants_grad(x, grad_sources):
         raise NotImplementedError("no backward kernel for this module / plan yet: call it under "
                                   "torch.no_grad() (or freeze the parameters)")
@@ -217,6 +215,33 @@ class _PlanFunction(torch.autograd.Function):
             grads.append(gp[off:off + n].view(shp) if (need_p and ctx.needs_input_grad[3 + i]) else None)
             off += n
         return (gx, None, None) + tuple(grads)
+
+
+class _PlanFunction64(torch.autograd.Function):
+    """The float64 features of a plan (`model.double()`): forward = molann_features_f64, backward =
+    molann_features_backward_f64 (everything recomputed in double from x).  The MLP of a float64 model is torch's."""
+
+    @staticmethod
+    def forward(ctx, x, entry):
+        out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float64, device=x.device)
+        entry.plan.features_f64(x, out)
+        ctx.save_for_backward(x)
+        ctx.entry = entry
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if torch.is_grad_enabled():
+            raise RuntimeError("molann_amd: the backward kernel is first-order only; create_graph=True (double "
+                               "backward, e.g. a loss on forces) is not supported")
+        (x,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if g.dtype != torch.float64:
+            g = g.double()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            ctx.entry.plan.features_backward_f64(x, g, gx)
+        return gx, None
 
 
 def _device_buffer(ref_x, x):
@@ -397,6 +422,8 @@ class AlignmentLayer(_PlanOwner, torch.nn.Module):
             entry = _get_entry(self, x, "align_grad", build)
             with torch.cuda.device(x.device):
                 entry.sync_ref(_device_buffer(self.ref_x, x))
+                if x.dtype == torch.float64:
+                    return _PlanFunction64.apply(x, entry).view(x.shape[0], self.input_atom_num, 3)
                 if not entry.plan.supports_backward():
                     raise NotImplementedError("no backward kernel for this alignment plan (large frames): use torch.no_grad()")
                 return _PlanFunction.apply(x, entry, False).view(x.shape[0], self.input_atom_num, 3)
@@ -499,6 +526,8 @@ def _run_features(feature_owner, x, align_layer, plan_owner=None):
         with torch.cuda.device(x.device):
             if align_layer is not None:
                 entry.sync_ref(_device_buffer(align_layer.ref_x, x))
+            if _wants_grad(x):
+                return _PlanFunction64.apply(x, entry)
             out = torch.empty((x.shape[0], entry.plan.feature_dim), dtype=torch.float64, device=x.device)
             entry.plan.features_f64(x, out)
         return out
@@ -670,6 +699,9 @@ class MolANN(_PlanOwner, torch.nn.Module):
         x = _device_input(x, grad_sources=st["params"], backward_ok=True)
         if x.shape[0] == 0:
             return torch.empty((0, st["out_dim"]), dtype=x.dtype, device=x.device)
+        if x.dtype == torch.float64 and _wants_grad(x, st["params"]):
+            # float64 training / forces: features and their gradient from the float64 kernels, ann_layers as the torch module it is
+            return self.ann_layers(self.preprocessing_layer(x))
         if x.dtype == torch.float64:
             # `model.double()(x.double())`: the float64 kernels, the Linear parameters read as they are
             lins = st["linears"]

@@ -957,6 +957,103 @@ __global__ __launch_bounds__(256) void frames_f64_kernel(const double* __restric
     }
 }
 
+// dL/dx of frames_f64_kernel's features, in double: the structure of frames_wave_bwd_kernel (one wave per frame, the frame's
+// gradient row zeroed, every contribution a double atomic into it) on the float64 forward's own formulas (centroid, then
+// H = sum (p - c) ref^T).  The reference differentiates its float64 forward with autograd.
+__global__ __launch_bounds__(256) void frames_bwd_f64_kernel(const double* __restrict__ x, const double* __restrict__ gout, double* __restrict__ gx,
+                                                             const int* __restrict__ align_idx, const double* __restrict__ ref64,
+                                                             const ItemDev* __restrict__ items, F64Args a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const long frame_dw = 3l * a.n_inp;
+    const bool has_align = a.n_align > 0;
+    for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
+        const double* xf = x + f * frame_dw;
+        double* gxf = gx + f * frame_dw;
+        const double* gf = gout + f * (long)a.out_cols;
+        for (long c = lane; c < frame_dw; c += 64) gxf[c] = 0.0;
+        double R[9] = {1., 0., 0., 0., 1., 0., 0., 0., 1.};
+        double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+        V3d c = v3d(0., 0., 0.);
+        if (has_align) {
+            double sx = 0., sy = 0., sz = 0.;
+            for (int i = lane; i < a.n_align; i += 64) { const V3d p = load_atom_f64(xf, align_idx[i]); sx += p.x; sy += p.y; sz += p.z; }
+            const double inv_a = 1.0 / (double)a.n_align;
+            c = v3d(wave_sum(sx) * inv_a, wave_sum(sy) * inv_a, wave_sum(sz) * inv_a);
+            double g = 0.;
+            for (int i = lane; i < a.n_align; i += 64) {
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3d p = load_atom_f64(xf, align_idx[i]) - c;
+                g = fma(p.x, p.x, fma(p.y, p.y, fma(p.z, p.z, g)));
+                h[0] = fma(p.x, rx, h[0]); h[1] = fma(p.x, ry, h[1]); h[2] = fma(p.x, rz, h[2]);
+                h[3] = fma(p.y, rx, h[3]); h[4] = fma(p.y, ry, h[4]); h[5] = fma(p.y, rz, h[5]);
+                h[6] = fma(p.z, rx, h[6]); h[7] = fma(p.z, ry, h[7]); h[8] = fma(p.z, rz, h[8]);
+            }
+            g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            kabsch_rotation_t<double, double>(h, 0.5 * (g + ref64[3 * a.n_align + 3]) * 1.0001, R);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zero stores are acknowledged before the atomics below
+        double GR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+        V3d gsum = v3d(0., 0., 0.);
+        for (int it = lane; it < a.n_items; it += 64) {
+            const ItemDev d = items[it];
+            V3d pc[4], y[4], gy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pc[j] = load_atom_f64(xf, d.idx[j]);
+                if (has_align) pc[j] = pc[j] - c;
+                y[j] = has_align ? rotate(pc[j], R) : pc[j];
+                gy[j] = v3d(0., 0., 0.);
+            }
+            const int w = item_width(d.type);
+            const double g3[3] = {gf[d.col], w > 1 ? gf[d.col + 1] : 0.0, w > 2 ? gf[d.col + 2] : 0.0};
+            eval_item_backward_f64(d.type, y[0], y[1], y[2], y[3], g3, gy[0], gy[1], gy[2], gy[3]);
+            const int na = item_atoms(d.type);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < na) {
+                    const V3d g = gy[j];
+                    V3d gp = g;
+                    if (has_align) { // y = pc R :  G_R += pc^T g ,  g_p = g R^T
+                        GR[0] = fma(pc[j].x, g.x, GR[0]); GR[1] = fma(pc[j].x, g.y, GR[1]); GR[2] = fma(pc[j].x, g.z, GR[2]);
+                        GR[3] = fma(pc[j].y, g.x, GR[3]); GR[4] = fma(pc[j].y, g.y, GR[4]); GR[5] = fma(pc[j].y, g.z, GR[5]);
+                        GR[6] = fma(pc[j].z, g.x, GR[6]); GR[7] = fma(pc[j].z, g.y, GR[7]); GR[8] = fma(pc[j].z, g.z, GR[8]);
+                        gp = v3d(fma(g.z, R[2], fma(g.y, R[1], g.x * R[0])), fma(g.z, R[5], fma(g.y, R[4], g.x * R[3])),
+                                 fma(g.z, R[8], fma(g.y, R[7], g.x * R[6])));
+                        gsum = gsum + gp;
+                    }
+                    double* dst = gxf + 3 * d.idx[j];
+                    atomicAdd(dst, gp.x); atomicAdd(dst + 1, gp.y); atomicAdd(dst + 2, gp.z);
+                }
+            }
+        }
+        if (has_align) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) GR[i] = wave_sum(GR[i]);
+            gsum = v3d(wave_sum(gsum.x), wave_sum(gsum.y), wave_sum(gsum.z));
+            double GH[9];
+            kabsch_rotation_backward_t<double, double>(h, R, GR, GH);
+            const double inv_a = 1.0 / (double)a.n_align;
+            // H = sum_i (a_i - c) ref_i^T also depends on c through every p_i: - G_H (sum_j ref_j) / a per align atom.  The
+            // reference centres ref_x in float32, so in double the sum is ~1e-7, not 0: visible at this path's 1e-9 bar.
+            const double srx = ref64[3 * a.n_align], sry = ref64[3 * a.n_align + 1], srz = ref64[3 * a.n_align + 2];
+            const V3d cen = v3d(inv_a * (gsum.x + fma(GH[2], srz, fma(GH[1], sry, GH[0] * srx))),
+                                inv_a * (gsum.y + fma(GH[5], srz, fma(GH[4], sry, GH[3] * srx))),
+                                inv_a * (gsum.z + fma(GH[8], srz, fma(GH[7], sry, GH[6] * srx))));
+            for (int i = lane; i < a.n_align; i += 64) {
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                double* dst = gxf + 3 * align_idx[i];
+                atomicAdd(dst, fma(GH[2], rz, fma(GH[1], ry, GH[0] * rx)) - cen.x);
+                atomicAdd(dst + 1, fma(GH[5], rz, fma(GH[4], ry, GH[3] * rx)) - cen.y);
+                atomicAdd(dst + 2, fma(GH[8], rz, fma(GH[7], ry, GH[6] * rx)) - cen.z);
+            }
+        }
+    }
+}
+
 // ann_layers in double: one wave per frame, the activations ping-pong between two LDS rows, lane j computes units j,
 // j + 64, ... of a layer as one fma chain over the inputs (weights read from the caller's tensors as they are: the
 // torch.nn.Linear layout W[J][K], b[J]).
@@ -2968,6 +3065,22 @@ int molann_features_f64(const molann_plan* p, const double* x, int64_t n, double
     if (c != MOLANN_OK || n == 0) return c;
     snprintf(const_cast<molann_plan*>(p)->last_info, sizeof(p->last_info), "frames_f64_kernel (features)");
     return launch_f64(p, x, n, out, 0, (hipStream_t)stream);
+}
+
+// dL/dx of molann_features_f64 for the same x: grad_f[N, feature_dim] -> grad_x[N, n_inp, 3], everything in double
+int molann_features_backward_f64(const molann_plan* p, const double* x, const double* grad_f, int64_t n, double* grad_x, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (p->n_items <= 0) return MOLANN_E_STAGE;
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !grad_f || !grad_x) return MOLANN_E_NULL;
+    if ((((uintptr_t)x) & 7) || (((uintptr_t)grad_f) & 7) || (((uintptr_t)grad_x) & 7)) return MOLANN_E_ALIGNMENT;
+    F64Args a;
+    a.n_frames = n; a.n_inp = p->n_inp; a.n_align = p->n_align; a.n_items = p->n_items; a.out_cols = p->d_feat; a.mode = 0;
+    const int grid = grid_for(p, n, 4, 8);
+    hipLaunchKernelGGL(frames_bwd_f64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, grad_f, grad_x, p->d_align_idx, p->d_ref64, p->d_items, a);
+    snprintf(const_cast<molann_plan*>(p)->last_info, sizeof(p->last_info), "frames_bwd_f64_kernel");
+    return (int)hipGetLastError();
 }
 
 int molann_mlp_f64(const molann_plan* p, const double* f, int64_t n, const double* const* W, const double* const* b, double* out,

@@ -486,8 +486,8 @@ MOLANN_HD float act_derivative(int act, float z, float h) {
 // (tr(S) I - S) w = vee(R^T dH - dH^T R); hence G_H = R [n]x, n = (tr(S) I - S)^-1 vee(M - M^T), M = R^T G_R.
 // ([v]x = cross-product matrix of v.)  3x3 products and one 3x3 symmetric solve in T: double, or float where the forward's
 // Kabsch is float as well (plans whose items are all invariant under rigid motion).
-template <typename T>
-MOLANN_HD void kabsch_rotation_backward_t(const T (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
+template <typename T, typename RT = float>
+MOLANN_HD void kabsch_rotation_backward_t(const T (&H)[9], const RT (&R)[9], const RT (&GR)[9], RT (&GH)[9]) {
     T S[9], M[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -517,14 +517,85 @@ MOLANN_HD void kabsch_rotation_backward_t(const T (&H)[9], const float (&R)[9], 
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const T r0 = R[3 * a], r1 = R[3 * a + 1], r2 = R[3 * a + 2];
-        GH[3 * a + 0] = (float)(r1 * n2 - r2 * n1);
-        GH[3 * a + 1] = (float)(r2 * n0 - r0 * n2);
-        GH[3 * a + 2] = (float)(r0 * n1 - r1 * n0);
+        GH[3 * a + 0] = (RT)(r1 * n2 - r2 * n1);
+        GH[3 * a + 1] = (RT)(r2 * n0 - r0 * n2);
+        GH[3 * a + 2] = (RT)(r0 * n1 - r1 * n0);
     }
 }
 
 MOLANN_HD void kabsch_rotation_backward(const double (&H)[9], const float (&R)[9], const float (&GR)[9], float (&GH)[9]) {
     kabsch_rotation_backward_t<double>(H, R, GR, GH);
+}
+
+// ---- float64 reverse mode of the feature items (the reference differentiates its float64 forward with autograd too) ----
+MOLANN_HD V3d operator+(V3d a, V3d b) { return v3d(a.x + b.x, a.y + b.y, a.z + b.z); }
+MOLANN_HD V3d operator*(double s, V3d a) { return v3d(s * a.x, s * a.y, s * a.z); }
+MOLANN_HD void axpy(V3d& acc, double s, V3d a) { acc.x = fma(s, a.x, acc.x); acc.y = fma(s, a.y, acc.y); acc.z = fma(s, a.z, acc.z); }
+
+// eval_item_backward in double: the same formulas with exact divisions and square roots
+MOLANN_HD void eval_item_backward_f64(int type, V3d a0, V3d a1, V3d a2, V3d a3, const double (&g)[3], V3d& ga0, V3d& ga1, V3d& ga2,
+                                      V3d& ga3) {
+    switch (type) {
+    case IT_BOND: {
+        const V3d r = a1 - a0;
+        const double d2 = dot(r, r);
+        const double inv = d2 > 0.0 ? 1.0 / sqrt(d2) : 0.0;
+        axpy(ga1, g[0] * inv, r);
+        axpy(ga0, -g[0] * inv, r);
+        return;
+    }
+    case IT_ANGLE_COS:
+    case IT_ANGLE_VAL: {
+        const V3d u = a0 - a1, v = a2 - a1;
+        const double uu = dot(u, u), vv = dot(v, v), uv = dot(u, v);
+        const double inv_uv = 1.0 / (sqrt(uu) * sqrt(vv));
+        const double c = uv * inv_uv;
+        double gc = g[0];
+        if (type == IT_ANGLE_VAL) gc = -g[0] / sqrt(1.0 - c * c);
+        V3d gu = v3d(0., 0., 0.), gv = v3d(0., 0., 0.);
+        axpy(gu, gc * inv_uv, v); axpy(gu, -gc * c / uu, u);
+        axpy(gv, gc * inv_uv, u); axpy(gv, -gc * c / vv, v);
+        ga0 = ga0 + gu;
+        ga2 = ga2 + gv;
+        ga1 = ga1 - (gu + gv);
+        return;
+    }
+    case IT_DIHEDRAL_CS:
+    case IT_DIHEDRAL_VAL: {
+        const V3d r12 = a1 - a0, r23 = a2 - a1, r34 = a3 - a2;
+        const V3d n1 = cross(r12, r23), n2 = cross(r23, r34);
+        const double L2 = dot(r23, r23);
+        const double L = sqrt(L2);
+        const double n1r34 = dot(n1, r34);
+        const double C = dot(n1, n2), S = n1r34 * L;
+        const double rad2 = fma(C, C, S * S);
+        double gC, gS;
+        if (type == IT_DIHEDRAL_CS) {
+            const double inv_rad = 1.0 / sqrt(rad2);
+            const double proj = (g[0] * C + g[1] * S) * inv_rad * inv_rad * inv_rad;
+            gC = g[0] * inv_rad - proj * C;
+            gS = g[1] * inv_rad - proj * S;
+        } else {
+            gC = -g[0] * S / rad2;
+            gS = g[0] * C / rad2;
+        }
+        V3d gn1 = gC * n2; axpy(gn1, gS * L, r34);
+        const V3d gn2 = gC * n1;
+        V3d gr34 = (gS * L) * n1;
+        V3d gr23 = (L > 0.0 ? gS * n1r34 / L : 0.0) * r23;
+        const V3d gr12 = cross(r23, gn1);
+        gr23 = gr23 + cross(gn1, r12) + cross(r34, gn2);
+        gr34 = gr34 + cross(gn2, r23);
+        ga0 = ga0 - gr12;
+        ga1 = ga1 + (gr12 - gr23);
+        ga2 = ga2 + (gr23 - gr34);
+        ga3 = ga3 + gr34;
+        return;
+    }
+    default: // IT_POSITION
+        ga0 = ga0 + v3d(g[0], g[1], g[2]);
+        return;
+    }
 }
 
 } // namespace molann

@@ -310,10 +310,22 @@ std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int
     const c10::DeviceGuard guard(x.device());
     const bool align_only = desc[1] == KIND_ALIGN;
     auto e = entry_for(align_only ? align_as_features(desc) : desc, x, ref_x);
-    TORCH_CHECK(molann_plan_supports_backward(e->plan) == 1,
+    TORCH_CHECK(x.scalar_type() == at::kDouble || molann_plan_supports_backward(e->plan) == 1,
                 "no backward kernel for this plan (wide MLP / large frames / this activation): run it under torch.no_grad()");
     const int64_t n = x.size(0);
     const int64_t cols = e->kind == KIND_FORWARD ? e->out_dim : e->feature_dim;
+    if (x.scalar_type() == at::kDouble) { // float64: the features' backward in double (the MLP of a float64 model is ATen's)
+        TORCH_CHECK(e->kind != KIND_FORWARD && !need_params, "molann::run_backward: float64 gradients exist for the preprocessing only");
+        at::Tensor g = grad_out.to(at::kDouble).reshape({n, cols}).contiguous();
+        at::Tensor gx = need_x ? at::empty_like(x) : at::empty({0}, x.options());
+        if (n == 0 || !need_x) return {gx, at::empty({0}, x.options())};
+        hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+        std::lock_guard<std::mutex> lock(e->mu);
+        sync_live(*e, x, ref_x, weights, biases, stream);
+        check(molann_features_backward_f64(e->plan, x.data_ptr<double>(), g.data_ptr<double>(), n, gx.data_ptr<double>(), stream),
+              "molann_features_backward_f64");
+        return {gx, at::empty({0}, x.options())};
+    }
     at::Tensor g = grad_out.to(at::kFloat).reshape({n, cols}).contiguous();
     at::Tensor gx = need_x ? at::empty_like(x) : at::empty({0}, x.options());
     at::Tensor gp = need_params ? at::zeros({molann_plan_grad_params_size(e->plan)}, x.options()) : at::empty({0}, x.options());
@@ -574,13 +586,25 @@ at::Tensor activation(int64_t code, const at::Tensor& t) {
 
 at::Tensor run_autograd(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
                         std::vector<at::Tensor> biases) {
-    if (x.scalar_type() == at::kDouble) { // float64 is forward only: never record a graph for it
+    if (x.scalar_type() == at::kDouble) {
+        // float64 (`model.double()`): gradients for the preprocessing come from molann_features_backward_f64; the MLP of a
+        // float64 model under grad mode is ATen's (its parameters are read as they are anyway)
         bool needs = at::GradMode::is_enabled() && x.requires_grad();
         for (const auto& w : weights) needs = needs || (at::GradMode::is_enabled() && w.requires_grad());
         for (const auto& b : biases) needs = needs || (at::GradMode::is_enabled() && b.requires_grad());
-        TORCH_CHECK(!needs, "molann::run: the float64 kernels are forward only: call the float64 model under torch.no_grad()");
-        at::AutoDispatchBelowADInplaceOrView below;
-        return call_run(x, desc, ref_x, weights, biases);
+        if (!needs) {
+            at::AutoDispatchBelowADInplaceOrView below;
+            return call_run(x, desc, ref_x, weights, biases);
+        }
+        if (desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD) {
+            at::Tensor h = call_run(x, features_only(desc), ref_x, {}, {});
+            for (size_t l = 0; l < weights.size(); ++l) {
+                h = at::linear(h, weights[l], biases[l]);
+                if (l + 1 < weights.size()) h = activation(desc[7], h);
+            }
+            return h;
+        }
+        return RunFunction::apply(x, desc, ref_x, at::TensorList(weights), at::TensorList(biases));
     }
     // A fused plan without a backward kernel (MLP wider than 32, large frames, ELU / GELU / Softplus) that has to
     // record gradients: features and their gradient from the kernels (the plan without the MLP), the MLP as ATen

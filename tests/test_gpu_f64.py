@@ -51,8 +51,8 @@ def test_mixed_dtypes_raise_like_the_reference(hip_device):
         model = model.double()
         with pytest.raises(RuntimeError):
             model(c.x.to(hip_device))                    # float64 module, float32 input
-    with pytest.raises(NotImplementedError):
-        model(c.x.double().to(hip_device).requires_grad_(True))   # float64 is forward only
+    out = model(c.x.double().to(hip_device).requires_grad_(True))    # float64 under grad mode: a graph is recorded
+    assert out.requires_grad and out.dtype == torch.float64
 
 
 @pytest.mark.parametrize("name", ["align_backbone_rigid", "features_C3p", "molann_C3", "molann_C4_small"])
@@ -68,5 +68,112 @@ def test_scripted_float64(name, hip_device):
     assert torch.equal(got, eager)
     scale = max(1.0, float(c.out_f64.abs().max()))
     assert float((got.cpu() - c.out_f64).abs().max()) <= 1e-10 * scale
-    with pytest.raises(RuntimeError):
-        scripted(x.clone().requires_grad_(True))
+    xg = x.clone().requires_grad_(True)               # under grad mode the scripted float64 model records a graph too
+    out = scripted(xg)
+    out.sum().backward()
+    xe = x.clone().requires_grad_(True)
+    model(xe).sum().backward()
+    assert out.requires_grad and torch.equal(xg.grad, xe.grad)
+
+
+# ---- float64 gradients (the reference differentiates its float64 forward with autograd): the preprocessing through
+# molann_features_backward_f64, the MLP as the torch module it is ----------------------------------------------------------
+import os
+
+import numpy as np
+
+from golden_util import GOLDEN_DIR
+
+
+@pytest.mark.parametrize("name", ["grad_molann_C1", "grad_molann_C3", "grad_features_C2", "grad_features_C3_val",
+                                  "grad_features_C3p"])
+def test_float64_gradients_match_reference_float64_autograd(name, hip_device):
+    from test_gpu_backward import _model_from_golden
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    model = _model_from_golden(d, hip_device).double()
+    x = torch.from_numpy(d["x"]).double().to(hip_device).requires_grad_(True)
+    out = model(x)
+    assert out.dtype == torch.float64 and out.requires_grad
+    s = max(1.0, float(np.abs(d["out_f64"]).max()))
+    assert float(np.abs(out.detach().cpu().numpy() - d["out_f64"]).max()) <= 1e-10 * s
+    (out * torch.from_numpy(d["G"]).double().to(hip_device)).sum().backward()
+    torch.cuda.synchronize()
+    s = max(1e-3, float(np.abs(d["gx_f64"]).max()))
+    assert float(np.abs(x.grad.cpu().numpy() - d["gx_f64"]).max()) <= 1e-9 * s
+    for i, p in enumerate(model.parameters()):
+        want = d["gp%d_f64" % i]
+        assert float(np.abs(p.grad.cpu().numpy() - want).max()) <= 1e-9 * max(1e-3, float(np.abs(want).max()))
+
+
+def test_float64_gradients_of_each_module_and_of_scripted_models(hip_device):
+    """AlignmentLayer / FeatureLayer / PreprocessingANN / MolANN in double against torch autograd through the fp64 oracle, eager
+    and scripted; parameters-only and x-only requests."""
+    import warnings
+    from molann_amd import workloads as wl
+    from oracle import molann_oracle as mo
+    w = wl.get_workload("C3")
+    model = wl.build_model(w, hip_device).double()
+    n = 333
+    x = w.make_frames(n, seed=21).double()
+    G = torch.randn((n, 8), generator=torch.Generator().manual_seed(3)).double()
+    feats = [(t, [a - 1 for a in atoms]) for t, atoms in w.features]
+    al = [a - 1 for a in w.align]
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[al])).double()
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    xx = x.clone().requires_grad_(True)
+    ws = [l.weight.detach().cpu().clone().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().clone().requires_grad_(True) for l in lins]
+    (mo.molann_forward(xx, feats, ws, bs, w.use_angle_value, al, ref_x) * G).sum().backward()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scripted = torch.jit.script(model)
+    for m in (model, scripted):
+        for p in model.parameters():
+            p.grad = None
+        xg = x.to(hip_device).requires_grad_(True)
+        (m(xg) * G.to(hip_device)).sum().backward()
+        assert float((xg.grad.cpu() - xx.grad).abs().max()) <= 1e-9 * max(1e-3, float(xx.grad.abs().max()))
+        for lin, wt, bt in zip(lins, ws, bs):
+            assert float((lin.weight.grad.cpu() - wt.grad).abs().max()) <= 1e-9 * max(1e-3, float(wt.grad.abs().max()))
+            assert float((lin.bias.grad.cpu() - bt.grad).abs().max()) <= 1e-9 * max(1e-3, float(bt.grad.abs().max()))
+    # x is data: parameter gradients only
+    for p in model.parameters():
+        p.grad = None
+    (model(x.to(hip_device)) * G.to(hip_device)).sum().backward()
+    assert float((lins[0].weight.grad.cpu() - ws[0].grad).abs().max()) <= 1e-9 * max(1e-3, float(ws[0].grad.abs().max()))
+    # the aligned frame and the features on their own
+    pp = model.preprocessing_layer
+    xg = x.to(hip_device).requires_grad_(True)
+    Gf = torch.randn((n, pp.output_dimension()), generator=torch.Generator().manual_seed(4)).double()
+    (pp(xg) * Gf.to(hip_device)).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    (mo.preprocessing_forward(xo, feats, w.use_angle_value, al, ref_x) * Gf).sum().backward()
+    assert float((xg.grad.cpu() - xo.grad).abs().max()) <= 1e-9 * max(1e-3, float(xo.grad.abs().max()))
+    xg = x.to(hip_device).requires_grad_(True)
+    Ga = torch.randn((n, w.n_atoms, 3), generator=torch.Generator().manual_seed(5)).double()
+    (pp.align_layer(xg) * Ga.to(hip_device)).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    (mo.align_forward(xo, al, ref_x) * Ga).sum().backward()
+    assert float((xg.grad.cpu() - xo.grad).abs().max()) <= 1e-9 * max(1e-3, float(xo.grad.abs().max()))
+
+
+def test_float64_gradients_on_large_frames(hip_device):
+    from molann_amd import workloads as wl
+    from oracle import molann_oracle as mo
+    big = wl.get_workload("C4")
+    model = wl.build_model(big, hip_device).double()
+    n = 5
+    x = big.make_frames(n, seed=3).double()
+    xg = x.to(hip_device).requires_grad_(True)
+    G = torch.randn((n, big.out_dim()), generator=torch.Generator().manual_seed(4)).double()
+    (model(xg) * G.to(hip_device)).sum().backward()
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    xx = x.clone().requires_grad_(True)
+    ws = [l.weight.detach().cpu().clone().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().clone().requires_grad_(True) for l in lins]
+    al = [a - 1 for a in big.align]
+    ref_x = mo.center_reference(torch.from_numpy(big.ref_xyz[al])).double()
+    want = mo.molann_forward(xx, [(t, [a - 1 for a in atoms]) for t, atoms in big.features], ws, bs, big.use_angle_value, al, ref_x)
+    (want * G).sum().backward()
+    assert float((xg.grad.cpu() - xx.grad).abs().max()) <= 1e-9 * max(1e-6, float(xx.grad.abs().max()))
+    assert float((lins[0].weight.grad.cpu() - ws[0].grad).abs().max()) <= 1e-9 * max(1e-6, float(ws[0].grad.abs().max()))
