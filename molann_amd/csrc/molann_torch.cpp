@@ -272,7 +272,7 @@ at::Tensor run_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::
     hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
     std::lock_guard<std::mutex> lock(e->mu);
     sync_live(*e, x, ref_x, weights, biases, stream);
-    if (x.scalar_type() == at::kDouble) { // `model.double()(x.double())`: the float64 entry points, forward only
+    if (x.scalar_type() == at::kDouble) { // `model.double()(x.double())`: the float64 entry points
         const double* xd = x.data_ptr<double>();
         double* od = out.data_ptr<double>();
         if (e->kind == KIND_ALIGN) check(molann_align_f64(e->plan, xd, n, od, stream), "molann_align_f64");
