@@ -1839,6 +1839,8 @@ struct JitSpec { // what the specialised kernel is compiled for
     int waves_per_eu = 2;             // occupancy the backward kernel is compiled for (amdgpu_waves_per_eu)
     int nbuf = 1;
     bool save_feat = false;           // forward kernel: also writes the features (training; molann_forward_train_f32)
+    bool frag_lds = false;            // one-pass backward: weight fragments in an LDS image at img_off instead of registers
+    int img_off = 0;
     // forward kernel: loader / consumer block around a ring of tile slots (molann_lane_jit.inc)
     int nload = 1;                    // loaders per block
     int ncons = 0, nslot = 0, depth = 0, ring_off = 0, tile_stride = 0, fb_off = 0, fb_bytes = 0, lds_block = 0, bpc = 0;
@@ -1997,12 +1999,30 @@ std::string jit_source_mlp_bwd(const JitSpecBox& b, int wpb) {
 
 // One-pass backward (molann_bwd_ring.inc): loaders + consumers around the ring of compact tiles; every consumer owns a
 // buffer that is MLP scratch, gradient tile and parameter sums in turn.  Two waves per SIMD (256 VGPRs each).
+// fragments of the weights the one-pass backward keeps per lane (molann_bwd_ring.inc: frag_ids())
+int bwd_ring_frags(const JitSpec& j) {
+    int n = 0;
+    for (int l = 0; l < j.n_layers; ++l)
+        for (int b = 0; b < 2; ++b) {
+            for (int s = 0; s < 8; ++s) {
+                if (l + 1 < j.n_layers && 16 * b < j.dims[l + 1] && 4 * s < j.dims[l]) ++n;
+                if (16 * b < j.dims[l] && 4 * s < j.dims[l + 1]) ++n;
+            }
+            if (l + 1 < j.n_layers && 16 * b < j.dims[l + 1]) n += 4;
+        }
+    return n;
+}
+
 bool bwd_ring_geometry(JitSpec& j, int n_params) {
     const int tile = ceil_to(64 * 16 * (int)j.win.size(), 16);
     const int rows = j.n_layers > 0 ? mlp_bwd_rows(j.dims, j.act) : 0;
     const int cbuf = ceil_to(std::max(std::max(64 * 12 * j.n_inp, rows * 68 * 4), std::max(16, n_params * 4)), 16);
     const int header = 256;
     j.bpc = 1;
+    // weight fragments: in registers up to the C3 class (a few dozen), beyond that in an LDS image shared by the block
+    const int frags = bwd_ring_frags(j);
+    j.frag_lds = frags > 40;
+    const int img = j.frag_lds ? frags * 256 : 0;
     // With an MLP the consumers are bound by their SIMDs' issue cycles (matrix and vector instructions of a SIMD do not overlap:
     // C3 takes 114 us per 1 M frames without the gradient tile whether 4 or 7 consumers work on it), the stream needs one
     // loader, and the seventh consumer shortens the per-wave tail of the gradient tile (152 -> 145 us).
@@ -2013,7 +2033,7 @@ bool bwd_ring_geometry(JitSpec& j, int n_params) {
     }
     for (int ncons = c0; ncons >= 2; --ncons) {
         const int nload = ncons >= 4 ? ld0 : 1;
-        const long nslot = std::min<long>(16, (163840 - header - (long)ncons * cbuf) / tile);
+        const long nslot = std::min<long>(16, (163840 - header - img - (long)ncons * cbuf) / tile);
         if (nslot < 2 * nload) continue;
         j.ncons = ncons; j.nload = nload; j.nslot = (int)nslot;
         j.depth = std::min(6, 63 / std::max(1, (int)j.win.size()));
@@ -2022,7 +2042,8 @@ bool bwd_ring_geometry(JitSpec& j, int n_params) {
         j.tile_stride = tile;
         j.fb_off = header + j.nslot * tile;
         j.fb_bytes = cbuf;
-        j.lds_block = j.fb_off + j.ncons * cbuf;
+        j.img_off = j.fb_off + j.ncons * cbuf;
+        j.lds_block = j.img_off + img;
         return true;
     }
     return false;
@@ -2062,6 +2083,8 @@ std::string jit_preamble(const JitSpec& j) {
     K("NCONS", j.ncons); K("NLOAD", j.nload); K("LDS_BLOCK", j.lds_block); K("NSLOT", j.nslot); K("DEPTH", j.depth); K("RING_OFF", j.ring_off); K("TILE_STRIDE", j.tile_stride);
     K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes);
     s += j.save_feat ? "constexpr bool SAVE_FEAT = true;\n" : "constexpr bool SAVE_FEAT = false;\n";
+    s += j.frag_lds ? "constexpr bool FRAG_LDS = true;\n" : "constexpr bool FRAG_LDS = false;\n";
+    K("IMG_OFF", j.img_off);
     {   // waves per SIMD the forward kernel must fit (its register budget): every wave of the (NCONS + 1)-wave blocks
         // a CU is to hold - the loader waves carry the consumers' allocation
         const int waves = (j.ncons + j.nload) * std::max(1, j.bpc);

@@ -369,3 +369,35 @@ def test_one_pass_backward_against_the_two_kernel_path(cfg, hip_device, monkeypa
         torch.cuda.synchronize()
         assert torch.equal(gx0, gx1) and torch.equal(gx0, got[0])
         assert float((gp0 - gp1).abs().max()) <= 1e-5 * max(1.0, float(gp0.abs().max()))
+
+
+@pytest.mark.parametrize("dims", [[6, 32, 32, 8], [6, 32, 32, 32, 4], [6, 16, 16, 16, 2]])
+def test_one_pass_backward_with_deeper_mlps(dims, hip_device, monkeypatch):
+    """Three and four Linear layers: the one-pass kernel keeps the weight fragments in an LDS image (FRAG_LDS) where they do
+    not fit the registers; against the two-kernel path and, for the parameters, fp64 autograd of ann_layers."""
+    import copy
+    w = wl.get_workload("C3")
+    base = wl.build_model(w, hip_device)
+    torch.manual_seed(sum(dims))
+    model = MolANN(base.preprocessing_layer, create_sequential_nn(dims).to(hip_device))
+    n = 4100
+    x = w.make_frames(n, seed=14).to(hip_device).requires_grad_(True)
+    G = torch.randn((n, dims[-1]), generator=torch.Generator().manual_seed(6)).to(hip_device)
+    (model(x) * G).sum().backward()
+    assert model.plan_for(x).backward_kind() == 2
+    monkeypatch.setenv("MOLANN_NO_RING_BWD", "1")
+    model2 = MolANN(base.preprocessing_layer, copy.deepcopy(model.ann_layers))
+    x2 = x.detach().clone().requires_grad_(True)
+    (model2(x2) * G).sum().backward()
+    assert model2.plan_for(x2).backward_kind() == 1
+    s = max(1e-3, float(x2.grad.abs().max()))
+    assert float((x.grad - x2.grad).abs().max()) <= 2e-5 * s
+    with torch.no_grad():
+        f = base.preprocessing_layer(x.detach())
+    f64 = f.double().cpu().requires_grad_(True)
+    nn64 = copy.deepcopy(model.ann_layers).double().cpu()
+    (nn64(f64) * G.double().cpu()).sum().backward()
+    for p, p2, q in zip(model.ann_layers.parameters(), model2.ann_layers.parameters(), nn64.parameters()):
+        s = max(1e-3, float(q.grad.abs().max()))
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * s
+        assert float((p2.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * s

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: molann_backward_f32 alone (C ABI), per 1 M frames.   [WL=C3] python tools/time_bwd_only.py [frames]"""
+"""Diagnostic: molann_backward_f32 alone (C ABI), per 1 M frames.   [WL=C3] [DIMS=6,32,32,8] [MOLANN_NO_RING_BWD=1] python tools/time_bwd_only.py [frames]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +8,11 @@ dev = torch.device("cuda:0")
 w = wl.get_workload(os.environ.get("WL", "C3"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else w.frames
 model = wl.build_model(w, dev)
+if os.environ.get("DIMS"):          # another MLP behind the workload's features: DIMS=6,32,32,8
+    from molann_amd.ann import MolANN, create_sequential_nn
+    dims = [int(v) for v in os.environ["DIMS"].split(",")]
+    model = MolANN(model.preprocessing_layer, create_sequential_nn(dims).to(dev))
+    w.mlp_dims = dims
 x = w.make_frames(n, device=dev, seed=1).requires_grad_(True)
 model(x).sum().backward()
 def find_plan(m):
