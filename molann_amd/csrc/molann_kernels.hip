@@ -1879,7 +1879,7 @@ std::vector<int> compact_windows(const std::vector<int>& slot_atoms, int n_inp) 
 // are zeros in registers).  A block is NCONS consumers + 1 loader; blocks <= 64 KiB (the LDS-DMA destination offset
 // is 16 bits).  Preference: 8 consumers per CU (two per SIMD: the arithmetic saturates the vector ALU there), then
 // the deepest ring, then the fewest blocks (= loader waves).
-void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fallback_cols) {
+void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fallback_cols, int max_cons = 14) {
     const int tile = ceil_to(64 * 16 * (int)j.win.size(), 16);
     const int fb = ceil_to(std::max(1, staging_rows) * FB_STRIDE * 4, 16);
     // One block per CU: 14 consumer waves + 2 loaders = four waves per SIMD (the kernel is built for <= 128 VGPRs).
@@ -1887,7 +1887,7 @@ void jit_geometry(JitSpec& j, molann_plan::LaneGeom& g, int staging_rows, int fa
     // the loaded HBM latency (~4 us, tools/stamps.py) needs ~120 KB in flight per CU for 6 TB/s; the consumers beyond
     // two per SIMD add no vector-ALU rate but keep the SIMD issuing while others wait (LDS, MFMA results, a tile).
     j.bpc = 1;
-    j.ncons = 14;
+    j.ncons = max_cons;
     j.nload = 2;
     const int header = 256;
     long nslot = 0;
@@ -2761,8 +2761,31 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             rc = jit_compile(jit_source(j), code, log, "-fno-slp-vectorize");
             hipModule_t mod = nullptr;
             hipFunction_t fn = nullptr;
-            if (rc != 0 || hipModuleLoadData(&mod, code.data()) != hipSuccess ||
-                hipModuleGetFunction(&fn, mod, "molann_lane_jit") != hipSuccess) {
+            bool loaded = rc == 0 && hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "molann_lane_jit") == hipSuccess;
+            int scratch = 0;
+            if (loaded && j.ncons > 10 && hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess && scratch > 0) {
+                // Three or four layers of 32 units: the weight fragments do not fit the 128 registers of four waves per SIMD and the
+                // build spills.  Ten consumers (three waves per SIMD, 168 registers) serve the stream as well as fourteen.
+                JitSpec j3 = j;
+                molann_plan::LaneGeom g3;
+                memset(&g3, 0, sizeof(g3));
+                jit_geometry(j3, g3, p->fused_mlp ? d_feat : cols_needed, cols_needed, 10);
+                std::vector<char> code3;
+                hipModule_t mod3 = nullptr;
+                hipFunction_t fn3 = nullptr;
+                int scratch3 = 0;
+                if (g3.ok && jit_compile(jit_source(j3), code3, log, "-fno-slp-vectorize") == 0 && hipModuleLoadData(&mod3, code3.data()) == hipSuccess &&
+                    hipModuleGetFunction(&fn3, mod3, "molann_lane_jit") == hipSuccess &&
+                    hipFuncGetAttribute(&scratch3, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn3) == hipSuccess && scratch3 < scratch) {
+                    (void)hipModuleUnload(mod);
+                    mod = mod3; fn = fn3; code.swap(code3);
+                    j = j3; p->jit_geom = g3;
+                    if (p->spec) p->spec->j = j;
+                } else if (mod3) {
+                    (void)hipModuleUnload(mod3);
+                }
+            }
+            if (!loaded) {
                 if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann jit failed rc=%d\n%s\n", rc, log.c_str());
                 if (mod) (void)hipModuleUnload(mod);
             } else {

@@ -40,3 +40,6 @@ print("backward x + params : %7.1f us   %s" % (timeit(lambda: plan.backward(xd, 
 print("backward x only     : %7.1f us" % timeit(lambda: plan.backward(xd, g, gx, None)))
 if has_p:
     print("backward params only: %7.1f us" % timeit(lambda: plan.backward(xd, g, None, gp)))
+if has_p:
+    o = torch.empty((n, w.out_dim()), device=dev)
+    print("forward_packed      : %7.1f us   %s" % (timeit(lambda: plan.forward_packed(xd, o)), plan.last_launch_info()[:100]))
