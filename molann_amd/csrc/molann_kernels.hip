@@ -1237,6 +1237,143 @@ __global__ __launch_bounds__(256) void frames_wave_bwd_kernel(const float* __res
     }
 }
 
+// frames_wave_bwd_gather_kernel: the same gradient without atomics (they were 9/10 of frames_wave_bwd_kernel's time: C4 80 us per
+// 1000 frames against 8 for the forward with the same scattered loads).  Items (lanes) leave their atoms' gradients g_y in the
+// wave's LDS buffer; then every TOUCHED ATOM (lanes again) adds up its own contributions - the lists are made at plan creation
+// (bw_atoms: touched atoms; bw_ptr / bw_list: CSR of (item, atom-of-item) pairs per touched atom; bw_align: its place in the
+// alignment set or -1) - rotates the sum back once, adds the alignment terms and stores its three floats behind the zero-fill.
+struct BwGatherArgs { int n_touched, lds_per_wave; };
+__global__ __launch_bounds__(256) void frames_wave_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                                     float* __restrict__ gx, const int* __restrict__ align_idx,
+                                                                     const float* __restrict__ ref, const double* __restrict__ ref64,
+                                                                     const ItemDev* __restrict__ items, const int* __restrict__ bw_atoms,
+                                                                     const int* __restrict__ bw_ptr, const int* __restrict__ bw_list,
+                                                                     const int* __restrict__ bw_align, PreArgs a, BwGatherArgs b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    float* gyb = (float*)(smem + (size_t)wave * b.lds_per_wave);   // [item][atom of item][xyz]
+    const auto refc = as_const(ref);
+    const bool has_align = a.n_align > 0;
+
+    for (long f = (long)blockIdx.x * wpb + wave; f < a.n_frames; f += (long)gridDim.x * wpb) {
+        const float* xf = x + f * (long)a.frame_dw;
+        float* gxf = gx + f * (long)a.frame_dw;
+        const float* gf = gout + f * (long)a.out_cols;
+        // ---- 0. zero this frame's gradient row
+        if (a.out_wide && (a.frame_dw & 3) == 0) {
+            for (int c = lane; c < (a.frame_dw >> 2); c += 64) ((f32x4*)gxf)[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int c = lane; c < a.frame_dw; c += 64) gxf[c] = 0.f;
+        }
+        // ---- 1. forward recompute: centre, covariance, rotation (as frames_wave_bwd_kernel)
+        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        double h[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+        V3 c0 = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
+        if (has_align) {
+            const int k0 = as_const(align_idx)[0];
+            c0 = load_atom(xf, k0);
+            float sx = 0.f, sy = 0.f, sz = 0.f, g = 0.f;
+#pragma unroll 4
+            for (int i = lane; i < a.n_align; i += 64) {
+                const int k = align_idx[i];
+                const double rx = ref64[3 * i], ry = ref64[3 * i + 1], rz = ref64[3 * i + 2];
+                const V3 p = load_atom(xf, k) - c0;
+                sx += p.x; sy += p.y; sz += p.z;
+                g = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, g)));
+                const double px = p.x, py = p.y, pz = p.z;
+                h[0] = fma(px, rx, h[0]); h[1] = fma(px, ry, h[1]); h[2] = fma(px, rz, h[2]);
+                h[3] = fma(py, rx, h[3]); h[4] = fma(py, ry, h[4]); h[5] = fma(py, rz, h[5]);
+                h[6] = fma(pz, rx, h[6]); h[7] = fma(pz, ry, h[7]); h[8] = fma(pz, rz, h[8]);
+            }
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); g = wave_sum(g);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = wave_sum(h[i]);
+            const int cb = 3 * a.n_align;
+            const auto r64c = as_const(ref64);
+            const double srx = r64c[cb], sry = r64c[cb + 1], srz = r64c[cb + 2], gref = r64c[cb + 3];
+            const float inv_a = refc[cb + 4], fa = refc[cb + 5];
+            dl = v3(sx * inv_a, sy * inv_a, sz * inv_a);
+            const double dx = dl.x, dy = dl.y, dz = dl.z;
+            h[0] = fma(-dx, srx, h[0]); h[1] = fma(-dx, sry, h[1]); h[2] = fma(-dx, srz, h[2]);
+            h[3] = fma(-dy, srx, h[3]); h[4] = fma(-dy, sry, h[4]); h[5] = fma(-dy, srz, h[5]);
+            h[6] = fma(-dz, srx, h[6]); h[7] = fma(-dz, sry, h[7]); h[8] = fma(-dz, srz, h[8]);
+            const float gp = fmaxf(g - fa * dot(dl, dl), 0.f);
+            kabsch_rotation(h, 0.5 * ((double)gp + gref) * 1.0001, R);
+        }
+        // ---- 2. items: g_y of their atoms -> LDS;  G_R += p^T g_y,  sum of g_y
+        float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        V3 gysum = v3(0.f, 0.f, 0.f);
+        for (int it = lane; it < a.n_items; it += 64) {
+            const int4 d0 = ((const int4*)items)[2 * it];
+            const int2 d1 = ((const int2*)items)[4 * it + 2];
+            const int type = d0.x, col = d0.y;
+            const int idx[4] = {d0.z, d0.w, d1.x, d1.y};
+            V3 pc[4], y[4], gy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pc[j] = load_atom(xf, idx[j]);
+                if (has_align) pc[j] = (pc[j] - c0) - dl;
+                y[j] = has_align ? rotate(pc[j], R) : pc[j];
+                gy[j] = v3(0.f, 0.f, 0.f);
+            }
+            const int w = item_width(type);
+            float g3[3] = {gf[col], w > 1 ? gf[col + 1] : 0.f, w > 2 ? gf[col + 2] : 0.f};
+            eval_item_backward(type, y[0], y[1], y[2], y[3], g3, gy[0], gy[1], gy[2], gy[3]);
+            const int na = item_atoms(type);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const V3 g = j < na ? gy[j] : v3(0.f, 0.f, 0.f);
+                float* dst = gyb + (4 * it + j) * 3;
+                dst[0] = g.x; dst[1] = g.y; dst[2] = g.z;
+                if (has_align && j < na) {
+                    GR[0] = fmaf(pc[j].x, g.x, GR[0]); GR[1] = fmaf(pc[j].x, g.y, GR[1]); GR[2] = fmaf(pc[j].x, g.z, GR[2]);
+                    GR[3] = fmaf(pc[j].y, g.x, GR[3]); GR[4] = fmaf(pc[j].y, g.y, GR[4]); GR[5] = fmaf(pc[j].y, g.z, GR[5]);
+                    GR[6] = fmaf(pc[j].z, g.x, GR[6]); GR[7] = fmaf(pc[j].z, g.y, GR[7]); GR[8] = fmaf(pc[j].z, g.z, GR[8]);
+                    gysum = gysum + g;
+                }
+            }
+        }
+        // ---- 3. rotation backward; the centroid's share
+        float GH[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        V3 gcen = v3(0.f, 0.f, 0.f);
+        if (has_align) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) GR[i] = wave_sum(GR[i]);
+            gysum = v3(wave_sum(gysum.x), wave_sum(gysum.y), wave_sum(gysum.z));
+            kabsch_rotation_backward(h, R, GR, GH);
+            const V3 gs = v3(fmaf(gysum.z, R[2], fmaf(gysum.y, R[1], gysum.x * R[0])), fmaf(gysum.z, R[5], fmaf(gysum.y, R[4], gysum.x * R[3])),
+                             fmaf(gysum.z, R[8], fmaf(gysum.y, R[7], gysum.x * R[6])));   // sum of g_p = (sum of g_y) R^T
+            gcen = refc[3 * a.n_align + 4] * gs;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the zero stores are acknowledged, the g_y are in LDS
+        // ---- 4. touched atoms: own contributions summed, rotated back, alignment terms, plain stores
+        for (int t = lane; t < b.n_touched; t += 64) {
+            V3 g = v3(0.f, 0.f, 0.f);
+            const int k1 = bw_ptr[t + 1];
+            for (int k = bw_ptr[t]; k < k1; ++k) {
+                const float* src = gyb + 3 * bw_list[k];
+                g = g + v3(src[0], src[1], src[2]);
+            }
+            V3 gp = g;
+            if (has_align) {
+                gp = v3(fmaf(g.z, R[2], fmaf(g.y, R[1], g.x * R[0])), fmaf(g.z, R[5], fmaf(g.y, R[4], g.x * R[3])),
+                        fmaf(g.z, R[8], fmaf(g.y, R[7], g.x * R[6])));
+                const int i = bw_align[t];
+                if (i >= 0) {
+                    const float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+                    gp = gp + (v3(fmaf(GH[2], rz, fmaf(GH[1], ry, GH[0] * rx)), fmaf(GH[5], rz, fmaf(GH[4], ry, GH[3] * rx)),
+                                  fmaf(GH[8], rz, fmaf(GH[7], ry, GH[6] * rx))) - gcen);
+                }
+            }
+            float* dst = gxf + 3 * bw_atoms[t];
+            dst[0] = gp.x; dst[1] = gp.y; dst[2] = gp.z;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the LDS buffer is read before the next frame's items overwrite it
+    }
+}
+
 // =============================================================================================
 // mlp_mfma_kernel: wide MLP over precomputed features, one wave per 16-frame row block
 // =============================================================================================
@@ -1688,6 +1825,9 @@ struct molann_plan {
     int* d_ring_align_pos;
     ItemDev* d_ring_items;
     int ring_nd, ring_nwin;
+    // large frames, backward without atomics (frames_wave_bwd_gather_kernel): touched atoms, CSR of their (item, atom) pairs
+    int* d_bw_atoms; int* d_bw_ptr; int* d_bw_list; int* d_bw_align;
+    int bw_touched;
     int n_slots;
     bool regs_mode;
     int* d_slots;
@@ -2584,6 +2724,33 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     const size_t o_ring_win = carve(sizeof(int) * std::max<size_t>(1, ring_win.size()));
     const size_t o_ring_apos = carve(sizeof(int) * std::max<size_t>(1, ring_align_pos.size()));
     const size_t o_ring_items = carve(sizeof(ItemDev) * std::max<size_t>(1, ring_items.size()));
+    // backward of large frames without atomics: who contributes to which touched atom
+    std::vector<int> bw_atoms, bw_ptr, bw_list, bw_align;
+    if (!p->geom[0].ok && p->n_items > 0 && d->n_layers >= 0) {
+        std::vector<std::vector<int>> contrib(d->n_inp);
+        std::vector<int> al_of(d->n_inp, -1);
+        std::vector<char> touched(d->n_inp, 0);
+        for (size_t it = 0; it < items.size(); ++it)
+            for (int j = 0; j < item_atoms(items[it].type); ++j) { contrib[items[it].idx[j]].push_back((int)(4 * it + j)); touched[items[it].idx[j]] = 1; }
+        for (int i = 0; i < d->n_align; ++i) { if (al_of[d->align_idx[i]] < 0) al_of[d->align_idx[i]] = i; touched[d->align_idx[i]] = 1; }
+        bool repeated_align = false;
+        { std::vector<char> seen(d->n_inp, 0); for (int i = 0; i < d->n_align; ++i) { repeated_align = repeated_align || seen[d->align_idx[i]]; seen[d->align_idx[i]] = 1; } }
+        if (!repeated_align) {   // (an alignment set that names an atom twice keeps the atomics: the atom has two reference rows)
+            bw_ptr.push_back(0);
+            for (int a0 = 0; a0 < d->n_inp; ++a0)
+                if (touched[a0]) {
+                    bw_atoms.push_back(a0);
+                    bw_align.push_back(al_of[a0]);
+                    bw_list.insert(bw_list.end(), contrib[a0].begin(), contrib[a0].end());
+                    bw_ptr.push_back((int)bw_list.size());
+                }
+        }
+    }
+    p->bw_touched = (int)bw_atoms.size();
+    const size_t o_bw_atoms = carve(sizeof(int) * std::max<size_t>(1, bw_atoms.size()));
+    const size_t o_bw_ptr = carve(sizeof(int) * std::max<size_t>(1, bw_ptr.size()));
+    const size_t o_bw_list = carve(sizeof(int) * std::max<size_t>(1, bw_list.size()));
+    const size_t o_bw_align = carve(sizeof(int) * std::max<size_t>(1, bw_align.size()));
 
     size_t lane_floats = 0;
     if (p->fused_mlp) lane_floats = (size_t)d->n_layers * (1024 + 512) + 1024;
@@ -2676,6 +2843,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->d_ring_win = (int*)(p->blob + o_ring_win);
     p->d_ring_align_pos = (int*)(p->blob + o_ring_apos);
     p->d_ring_items = (ItemDev*)(p->blob + o_ring_items);
+    p->d_bw_atoms = (int*)(p->blob + o_bw_atoms); p->d_bw_ptr = (int*)(p->blob + o_bw_ptr);
+    p->d_bw_list = (int*)(p->blob + o_bw_list); p->d_bw_align = (int*)(p->blob + o_bw_align);
     p->d_wlane = (float*)(p->blob + o_wlane);
     p->d_wmfma = (void*)(p->blob + o_wmfma);
     p->d_work = (float*)(p->blob + o_work);
@@ -2719,6 +2888,12 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         if (e == hipSuccess) e = hipMemcpy(p->d_ring_items, ring_items.data(), sizeof(ItemDev) * ring_items.size(), hipMemcpyHostToDevice);
     }
 
+    if (e == hipSuccess && p->bw_touched > 0) {
+        e = hipMemcpy(p->d_bw_atoms, bw_atoms.data(), sizeof(int) * bw_atoms.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_bw_ptr, bw_ptr.data(), sizeof(int) * bw_ptr.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !bw_list.empty()) e = hipMemcpy(p->d_bw_list, bw_list.data(), sizeof(int) * bw_list.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_bw_align, bw_align.data(), sizeof(int) * bw_align.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { (void)hipFree(p->blob); delete p; return (int)e; }
     snprintf(p->last_info, sizeof(p->last_info), "(no launch yet)");
     if (p->work_frames > 0) {
@@ -3361,6 +3536,18 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
         if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_x) & 3)) return MOLANN_E_ALIGNMENT;
         PreArgs a;
         fill_pre_args(p, a, n, 0, p->d_feat, false, x, grad_x);
+        const int per_wave = ((p->n_items * 48 + 15) / 16) * 16;   // g_y of every item's four atoms
+        if (p->bw_touched > 0 && per_wave <= 65536 && getenv("MOLANN_BWD_ATOMICS") == nullptr) {
+            const int wpb = std::max(1, std::min(4, 65536 / per_wave));
+            const int bpc = std::max(1, std::min(8, 160 * 1024 / (wpb * per_wave)));
+            const int grid = grid_for(p, n, wpb, bpc);
+            BwGatherArgs b = {p->bw_touched, per_wave};
+            hipLaunchKernelGGL(frames_wave_bwd_gather_kernel, dim3(grid), dim3(64 * wpb), (size_t)wpb * per_wave, (hipStream_t)stream, x, grad_out,
+                               grad_x, p->d_align_idx, p->d_ref, p->d_ref64, p->d_items, p->d_bw_atoms, p->d_bw_ptr, p->d_bw_list, p->d_bw_align,
+                               a, b);
+            snprintf(p->last_info, sizeof(p->last_info), "frames_wave_bwd_gather_kernel grid=%d block=%d lds=%d", grid, 64 * wpb, wpb * per_wave);
+            return (int)hipGetLastError();
+        }
         const int wpb = 4;
         const int grid = grid_for(p, n, wpb, 8);
         hipLaunchKernelGGL(frames_wave_bwd_kernel, dim3(grid), dim3(64 * wpb), 0, (hipStream_t)stream, x, grad_out, grad_x,

@@ -157,7 +157,7 @@ def test_alignment_layer_gradient(hip_device):
 
 @pytest.mark.parametrize("cfg", ["C4", "C5"])
 def test_large_frames_gradients(cfg, hip_device):
-    """Wave-per-frame plans: dL/dx from frames_wave_bwd_kernel (features) chained with the torch MLP, parameter
+    """Wave-per-frame plans: dL/dx from frames_wave_bwd_gather_kernel (features) chained with the torch MLP, parameter
     gradients from torch; against autograd through the fp64 oracle."""
     big = wl.get_workload(cfg)
     model = wl.build_model(big, hip_device)
@@ -170,7 +170,7 @@ def test_large_frames_gradients(cfg, hip_device):
     y = model(xg)
     (y * G.to(hip_device)).sum().backward()
     from molann_amd.ann import last_launch_info
-    assert "frames_wave_bwd_kernel" in last_launch_info(model.preprocessing_layer)
+    assert "frames_wave_bwd_gather_kernel" in last_launch_info(model.preprocessing_layer)
     lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
     xx = x.double().requires_grad_(True)
     ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]

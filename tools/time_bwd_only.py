@@ -17,13 +17,16 @@ x = w.make_frames(n, device=dev, seed=1).requires_grad_(True)
 model(x).sum().backward()
 def find_plan(m):
     if hasattr(m, "_fast_state"):
-        return m.plan_for(x)
+        p = m.plan_for(x)
+        if p is not None and p.supports_backward():
+            return p
     for mod in m.modules():
         for e in getattr(mod, "_plans", lambda: {})().values():
             if hasattr(e, "plan") and e.plan.supports_backward():
                 return e.plan
 plan = find_plan(model)
-g = torch.randn((n, w.out_dim()), device=dev)
+cols = plan.out_dim if plan.grad_params_size() > 0 else plan.feature_dim
+g = torch.randn((n, cols), device=dev)
 xd = x.detach()
 gx = torch.empty_like(xd)
 gp = torch.zeros(max(1, plan.grad_params_size()), device=dev)
@@ -41,5 +44,5 @@ print("backward x only     : %7.1f us" % timeit(lambda: plan.backward(xd, g, gx,
 if has_p:
     print("backward params only: %7.1f us" % timeit(lambda: plan.backward(xd, g, None, gp)))
 if has_p:
-    o = torch.empty((n, w.out_dim()), device=dev)
+    o = torch.empty((n, cols), device=dev)
     print("forward_packed      : %7.1f us   %s" % (timeit(lambda: plan.forward_packed(xd, o)), plan.last_launch_info()[:100]))
