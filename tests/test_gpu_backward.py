@@ -401,3 +401,23 @@ def test_one_pass_backward_with_deeper_mlps(dims, hip_device, monkeypatch):
         s = max(1e-3, float(q.grad.abs().max()))
         assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * s
         assert float((p2.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * s
+
+
+def test_large_frames_backward_with_and_without_atomics(hip_device, monkeypatch):
+    """frames_wave_bwd_gather_kernel (contributions gathered per touched atom) against frames_wave_bwd_kernel (float atomics)."""
+    from molann_amd.ann import last_launch_info
+    big = wl.get_workload("C5")
+    pp = wl.build_model(big, hip_device).preprocessing_layer
+    n = 9
+    x = big.make_frames(n, seed=5).to(hip_device)
+    G = torch.randn((n, pp.output_dimension()), generator=torch.Generator().manual_seed(6)).to(hip_device)
+    grads = []
+    for atomics in (False, True):
+        if atomics:
+            monkeypatch.setenv("MOLANN_BWD_ATOMICS", "1")
+        xg = x.clone().requires_grad_(True)
+        (pp(xg) * G).sum().backward()
+        assert ("frames_wave_bwd_kernel" if atomics else "frames_wave_bwd_gather_kernel") in last_launch_info(pp)
+        grads.append(xg.grad)
+    s = max(1e-6, float(grads[1].abs().max()))
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * s
