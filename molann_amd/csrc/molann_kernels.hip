@@ -2132,6 +2132,9 @@ std::string jit_source_mlp_bwd(const JitSpecBox& b, int wpb) {
     for (int l = 0; l < j.n_layers; ++l) { goff.push_back(g); g += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1]; }
     arr("DIMS", dims); arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
     K("N_PARAMS", (int)g);
+    s += "constexpr bool FRAG_LDS = false;\n";   // this kernel's waves have the registers for their weight fragments
+    s += "#line 1 \"molann_mlp_tile.inc\"\n";
+    s += join_chunks(k_src_molann_mlp_tile_inc);
     s += "#line 1 \"molann_mlp_bwd.inc\"\n";
     s += join_chunks(k_src_molann_mlp_bwd_inc);
     return s;
@@ -2207,6 +2210,8 @@ std::string jit_source_bwd_ring(const JitSpecBox& b) {
     s += t;
     s += "#line 1 \"molann_ring.inc\"\n";
     s += join_chunks(k_src_molann_ring_inc);
+    s += "#line 1 \"molann_mlp_tile.inc\"\n";
+    s += join_chunks(k_src_molann_mlp_tile_inc);
     s += "#line 1 \"molann_bwd_ring.inc\"\n";
     s += join_chunks(k_src_molann_bwd_ring_inc);
     return s;
