@@ -421,3 +421,27 @@ def test_large_frames_backward_with_and_without_atomics(hip_device, monkeypatch)
         grads.append(xg.grad)
     s = max(1e-6, float(grads[1].abs().max()))
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * s
+
+
+def test_a_nan_frame_poisons_only_itself(hip_device):
+    """The one-pass backward reuses one LDS buffer per consumer for the MLP scratch and the gradient tile: a frame of NaNs must
+    not leak into the frames that buffer serves afterwards (x gradients; the parameter sums are NaN, as torch's would be)."""
+    w = wl.get_workload("C3")
+    model = wl.build_model(w, hip_device)
+    n = 64 * 2048 + 7                      # 8 tiles per block: the consumers that meet the NaN frames go on to other tiles
+    x = w.make_frames(n, seed=15).to(hip_device)
+    G = torch.randn((n, w.out_dim()), generator=torch.Generator().manual_seed(7)).to(hip_device)
+    xa = x.clone().requires_grad_(True)
+    (model(xa) * G).sum().backward()
+    bad = [3, 64 * 17 + 5]
+    xb = x.clone()
+    xb[bad] = float("nan")
+    xb.requires_grad_(True)
+    for p in model.parameters():
+        p.grad = None
+    (model(xb) * G).sum().backward()
+    keep = torch.ones(n, dtype=torch.bool, device=hip_device)
+    keep[bad] = False
+    assert torch.isfinite(xb.grad[keep]).all()
+    assert torch.equal(xb.grad[keep], xa.grad[keep])
+    assert torch.isnan(xb.grad[bad][:, [a - 1 for a in w.touched_atoms()]]).all()
