@@ -58,6 +58,20 @@ def test_backward_kernels_compile(name, mode, entry):
     assert entry in buf.value.decode()
 
 
+@pytest.mark.parametrize("dims,act", [([6, 32, 8], 0), ([6, 17, 5, 9, 2], 2), ([6, 30, 31], 5), ([6, 32, 32, 32, 4], 7), ([6, 4], 0),
+                                      ([6, 24, 24, 1], 1), ([6, 32, 32, 8], 5), ([6, 1, 1], 3)])
+@pytest.mark.parametrize("mode", [11, 19])
+def test_backward_kernels_compile_for_other_mlps(dims, act, mode):
+    """Host geometry (scratch rows, fragment image, LDS layout) against the kernels' own static_asserts, over layer counts, widths
+    and activations (SiLU keeps the pre-activations as well): the MLP half and the one-pass backward cross-compile."""
+    d, keep = _desc(wl.get_workload("C3"))
+    ld = (ctypes.c_int32 * len(dims))(*dims)
+    d.n_layers, d.layer_dims, d.activation = len(dims) - 1, ld, act
+    buf = ctypes.create_string_buffer(1 << 21)
+    rc = _capi.lib().molann_debug_jit(ctypes.byref(d), mode, buf, 1 << 21)
+    assert rc > 1000, (rc, buf.value.decode()[:3000])
+
+
 def test_large_frames_are_not_specialised():
     d, keep = _desc(wl.get_workload("C4"))
     rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 0, None, 0)
