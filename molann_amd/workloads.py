@@ -6,7 +6,6 @@ and the synthetic-frame distribution.  `bench.py`, the tests and
 `oracle/gen_golden.py` all build their inputs from here so that they agree.
 """
 
-import math
 
 import numpy as np
 import torch

@@ -3,7 +3,7 @@
 the frame size) against the wave-per-frame kernel (MOLANN_NO_JIT=1).  python tools/time_few_atoms_large_frame.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from molann_amd import workloads as wl
 from molann_amd.ann import AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn, last_launch_info
 from molann_amd.atomgroup import Universe

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: incremental cost of the stages on C3's system at full size (each variant gets its own
 plan-specialised kernel): features only, Kabsch + features, Kabsch + features + MLP."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from molann_amd import workloads as wl
