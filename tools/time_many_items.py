@@ -1,4 +1,4 @@
-import sys, time, itertools, torch, numpy as np
+import sys, time, itertools, torch
 sys.path.insert(0,'/root/repo')
 from molann_amd import workloads as wl
 from molann_amd.ann import AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn, last_launch_info
