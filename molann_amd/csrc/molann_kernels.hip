@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1944,6 +1945,7 @@ struct RtcApi {
     decltype(&hiprtcGetProgramLogSize) log_size;
     decltype(&hiprtcGetProgramLog) log;
     decltype(&hiprtcDestroyProgram) destroy;
+    decltype(&hiprtcVersion) version;   // optional: part of the code-object cache's key
     bool ok;
 };
 
@@ -1962,6 +1964,7 @@ const RtcApi* rtc_api() {
         a.log_size = (decltype(a.log_size))dlsym(h, "hiprtcGetProgramLogSize");
         a.log = (decltype(a.log))dlsym(h, "hiprtcGetProgramLog");
         a.destroy = (decltype(a.destroy))dlsym(h, "hiprtcDestroyProgram");
+        a.version = (decltype(a.version))dlsym(h, "hiprtcVersion");
         a.ok = a.create && a.compile && a.code_size && a.code && a.log_size && a.log && a.destroy;
         return a;
     }();
@@ -2319,6 +2322,35 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
     }
     std::vector<const char*> opts;
     for (auto& f : flags) opts.push_back(f.c_str());
+    // MOLANN_JIT_CACHE_DIR=<dir>: code objects kept on disk under a hash of everything they are made from (kernel text,
+    // molann_math.h, flags, the hipRTC version), so a process that builds a plan another one has built skips the compile
+    // (1.5-4 s per kernel).  Opt-in; a file that is missing, unreadable or of the wrong size is simply rebuilt.
+    std::string cache_file;
+    if (const char* dir = getenv("MOLANN_JIT_CACHE_DIR")) {
+        if (dir[0]) {
+            unsigned long long h = 1469598103934665603ull;   // FNV-1a, 64 bit
+            auto mix = [&](const std::string& t) { for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+            mix(src); mix(math);
+            for (auto& f : flags) mix(f);
+            int maj = 0, min = 0;
+            if (rtc->version) (void)rtc->version(&maj, &min);
+            char name[96];
+            snprintf(name, sizeof(name), "/molann_%016llx_%zu_rtc%d.%d.hsaco", h, src.size(), maj, min);
+            cache_file = std::string(dir) + name;
+            if (FILE* f = fopen(cache_file.c_str(), "rb")) {
+                std::vector<char> blob;
+                char buf[1 << 16];
+                size_t got;
+                while ((got = fread(buf, 1, sizeof(buf), f)) > 0) blob.insert(blob.end(), buf, buf + got);
+                fclose(f);
+                if (blob.size() > 64 && memcmp(blob.data(), "\177ELF", 4) == 0) {
+                    code.swap(blob);
+                    rtc->destroy(&prog);
+                    return 0;
+                }
+            }
+        }
+    }
     r = rtc->compile(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     rtc->log_size(prog, &ls);
@@ -2328,6 +2360,14 @@ int jit_compile(const std::string& src, std::vector<char>& code, std::string& lo
         rtc->code_size(prog, &cs);
         code.resize(cs);
         rtc->code(prog, code.data());
+        if (!cache_file.empty()) { // written under a temporary name and renamed: a reader never sees half a file
+            const std::string tmp = cache_file + ".tmp" + std::to_string((long)getpid());
+            if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+                fclose(f);
+                if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
+            }
+        }
     }
     rtc->destroy(&prog);
     return (int)r;

@@ -72,6 +72,29 @@ def test_backward_kernels_compile_for_other_mlps(dims, act, mode):
     assert rc > 1000, (rc, buf.value.decode()[:3000])
 
 
+def test_code_object_cache_on_disk(tmp_path, monkeypatch):
+    """MOLANN_JIT_CACHE_DIR: the second build of the same kernel is read from disk; a damaged file is rebuilt, not loaded."""
+    import os
+    import time
+    monkeypatch.setenv("MOLANN_JIT_CACHE_DIR", str(tmp_path))
+    d, keep = _desc(wl.get_workload("C2"))
+    buf = ctypes.create_string_buffer(1 << 20)
+    t0 = time.perf_counter()
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    t1 = time.perf_counter()
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 1 and open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    t2 = time.perf_counter()
+    assert t2 - t1 < 0.5 * (t1 - t0)                     # no compile the second time
+    open(os.path.join(tmp_path, files[0]), "wb").write(b"not a code object")
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"    # rebuilt and replaced
+    d2, keep2 = _desc(wl.get_workload("C3"))              # another plan: another file
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d2), 1, buf, 1 << 20) > 1000
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
+
+
 def test_large_frames_are_not_specialised():
     d, keep = _desc(wl.get_workload("C4"))
     rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 0, None, 0)
