@@ -18,6 +18,15 @@ def pytest_sessionstart(session):
     from molann_amd import _capi, script
     if not (os.path.exists(_capi.LIB_PATH) and os.path.exists(script.TORCH_LIB_PATH)):
         _capi.build_library()
+    # The suite builds the same few dozen plan-specialised kernels hundreds of times (every test makes its own models): keep
+    # their code objects for the length of the session.  Every distinct kernel is still compiled by hipRTC once.
+    if not os.environ.get("MOLANN_JIT_CACHE_DIR"):
+        import atexit
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix="molann_jit_")
+        os.environ["MOLANN_JIT_CACHE_DIR"] = d
+        atexit.register(shutil.rmtree, d, True)
 
 
 @pytest.fixture(scope="session")
