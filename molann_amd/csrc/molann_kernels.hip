@@ -2696,7 +2696,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     for (auto& it : items_slot)
         for (int i = 0; i < 4; ++i) it.idx[i] = slot(it.idx[i]);
     p->n_slots = (int)slots.size();
-    // (plan creation is setup time: MOLANN_DEBUG_NO_REGS / MOLANN_NO_JIT select the other generic modes here)
+    // (plan creation is setup time: MOLANN_NO_REGS / MOLANN_NO_JIT select the other generic modes here)
     p->regs_mode = p->n_items > 0 && p->n_items <= 64 && p->n_slots <= 16 && align_is_prefix &&
                    getenv("MOLANN_NO_REGS") == nullptr;
     memset(p->geom, 0, sizeof(p->geom));
