@@ -43,3 +43,43 @@ class GraphedForward(object):
         self.static_x.copy_(x)
         self.graph.replay()
         return self.static_y
+
+
+class GraphedForces(GraphedForward):
+    """Forward and vector-Jacobian product as two HIP graphs, for callers that differentiate a small batch at every step (a
+    collective variable inside an MD engine: the values first, then dV/dx for the cotangent dV/d(values) the engine forms).
+
+        g = GraphedForces(model, x_example)      # a MolANN served by one fused plan, parameters frozen
+        y = g(x)                                 # static buffer [n, d_out]
+        dx = g.vjp(dy)                           # static buffer [n, n_inp, 3]: sum_k dy[:, k] d y[:, k] / d x, for the x of the last g(x)
+
+    The backward graph holds one launch of `molann_backward_f32` (the one-pass kernel recomputes the forward from the static x:
+    nothing else links the two graphs), built and warmed before capture.  `recapture()` after changing parameters."""
+
+    def recapture(self):
+        super(GraphedForces, self).recapture()
+        x = self.static_x
+        plan = self.model.plan_for(x) if hasattr(self.model, "plan_for") else None
+        if plan is None or not plan.supports_backward():
+            raise NotImplementedError("GraphedForces needs a model served by one fused plan with a backward kernel")
+        self._plan = plan
+        self.static_dy = torch.zeros_like(self.static_y)
+        self.static_dx = torch.empty_like(x)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side), torch.cuda.device(x.device):
+            for _ in range(self._warmup):       # compiles the backward kernel outside the capture
+                plan.backward(x, self.static_dy, self.static_dx, None)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph), torch.cuda.device(x.device):
+            plan.backward(x, self.static_dy, self.static_dx, None)
+        return self
+
+    def vjp(self, dy):
+        if dy.shape != self.static_dy.shape:
+            raise ValueError("GraphedForces was captured for cotangents %s, got %s" % (tuple(self.static_dy.shape), tuple(dy.shape)))
+        self.static_dy.copy_(dy)
+        self.bwd_graph.replay()
+        return self.static_dx

@@ -302,6 +302,34 @@ def test_hip_graph_replay_matches_eager(hip_device):
             assert torch.equal(got.cpu(), want), cfg
 
 
+def test_hip_graph_forces_match_autograd(hip_device):
+    """GraphedForces: the values and the vector-Jacobian product of a small batch as two HIP graph replays (a collective variable
+    differentiated at every MD step), against eager autograd; with its latency per call."""
+    import time
+    from molann_amd.graph import GraphedForces
+    w = wl.get_workload("C3")
+    model = workload_model(w, hip_device).requires_grad_(False)
+    for n in (1, 64):
+        g = GraphedForces(model, w.make_frames(n, seed=1).to(hip_device))
+        for seed in (2, 3):
+            x = w.make_frames(n, seed=seed).to(hip_device)
+            dy = torch.randn((n, w.out_dim()), generator=torch.Generator().manual_seed(seed)).to(hip_device)
+            y = g(x).clone()
+            dx = g.vjp(dy).clone()
+            xe = x.clone().requires_grad_(True)
+            ye = model(xe)
+            (dxe,) = torch.autograd.grad(ye, xe, dy)
+            assert torch.equal(y, ye.detach())
+            assert float((dx - dxe).abs().max()) <= 1e-6 * max(1.0, float(dxe.abs().max()))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            g(x)
+            g.vjp(dy)
+        torch.cuda.synchronize()
+        print("GraphedForces, %d frame(s): %.1f us per values + forces" % (n, (time.perf_counter() - t0) / 200 * 1e6))
+
+
 def test_host_trajectory_streamer(hip_device):
     """Pinned double-buffered H2D/D2H around the forward gives the same rows as one resident batch."""
     from molann_amd.stream import stream_forward
