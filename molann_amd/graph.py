@@ -53,6 +53,9 @@ class GraphedForces(GraphedForward):
         y = g(x)                                 # static buffer [n, d_out]
         dx = g.vjp(dy)                           # static buffer [n, n_inp, 3]: sum_k dy[:, k] d y[:, k] / d x, for the x of the last g(x)
 
+    The full Jacobian of one frame's d_out values comes from the same two replays on a batch of d_out copies of the frame with the
+    identity as cotangent: `g = GraphedForces(model, x.expand(d_out, -1, -1).contiguous()); y = g(xr)[0]; J = g.vjp(torch.eye(d_out))`.
+
     The backward graph holds one launch of `molann_backward_f32` (the one-pass kernel recomputes the forward from the static x:
     nothing else links the two graphs), built and warmed before capture.  `recapture()` after changing parameters."""
 
