@@ -328,6 +328,18 @@ def test_hip_graph_forces_match_autograd(hip_device):
             g.vjp(dy)
         torch.cuda.synchronize()
         print("GraphedForces, %d frame(s): %.1f us per values + forces" % (n, (time.perf_counter() - t0) / 200 * 1e6))
+    # the whole Jacobian of one frame's values: a batch of d_out copies of the frame, the identity as cotangent
+    d_out = w.out_dim()
+    x1 = w.make_frames(1, seed=9).to(hip_device)
+    g = GraphedForces(model, x1.expand(d_out, -1, -1).contiguous())
+    y = g(x1.expand(d_out, -1, -1).contiguous())[0].clone()
+    J = g.vjp(torch.eye(d_out, device=hip_device)).clone()
+    xe = x1.clone().requires_grad_(True)
+    ye = model(xe)
+    assert torch.equal(y, ye.detach()[0])
+    for k in range(d_out):
+        (gk,) = torch.autograd.grad(ye[0, k], xe, retain_graph=True)
+        assert float((J[k] - gk[0]).abs().max()) <= 1e-6 * max(1.0, float(gk.abs().max()))
 
 
 def test_host_trajectory_streamer(hip_device):
