@@ -316,3 +316,29 @@ class Plan(object):
         buf = ctypes.create_string_buffer(256)
         lib().molann_plan_last_launch_info(self._handle, buf, 256)
         return buf.value.decode()
+
+
+def workload_desc(w):
+    """``(PlanDesc, keep)`` for a `molann_amd.workloads.Workload` (0-based indices, zero reference coordinates): what
+    `molann_debug_jit` cross-compiles a plan's specialised kernels from without a device.  `keep` holds the ctypes arrays
+    the description points into."""
+    d = PlanDesc()
+    d.abi_version, d.n_inp = ABI_VERSION, w.n_atoms
+    keep = []
+    I = lambda v: (ctypes.c_int32 * max(1, len(v)))(*v)  # noqa: E731
+    if w.align:
+        a, r = I([x - 1 for x in w.align]), (ctypes.c_float * (3 * len(w.align)))()
+        d.n_align, d.align_idx, d.ref_x = len(w.align), a, r
+        keep += [a, r]
+    ptr, flat = [0], []
+    for _, atoms in w.features:
+        flat += [x - 1 for x in atoms]
+        ptr.append(len(flat))
+    ft, fp, fi = I([t for t, _ in w.features]), I(ptr), I(flat)
+    d.n_features, d.feat_type, d.feat_ptr, d.feat_idx = len(w.features), ft, fp, fi
+    keep += [ft, fp, fi]
+    if w.mlp_dims:
+        ld = I(w.mlp_dims)
+        d.n_layers, d.layer_dims = len(w.mlp_dims) - 1, ld
+        keep.append(ld)
+    return d, keep

@@ -672,12 +672,7 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
             for (int r = 0; r < PR; ++r) {
                 if (!pon[r]) continue;
                 V3 p0 = pa[r][0], p1 = pa[r][1], p2 = pa[r][2], p3 = pa[r][3];
-                if (has_align) {
-                    p0 = rotate((p0 - c0) - dl, R);
-                    p1 = rotate((p1 - c0) - dl, R);
-                    p2 = rotate((p2 - c0) - dl, R);
-                    p3 = rotate((p3 - c0) - dl, R);
-                }
+                if (has_align) align_item_atoms(pt[r], p0, p1, p2, p3, c0, dl, R);
                 float v[3];
                 const int w = eval_item(pt[r], p0, p1, p2, p3, v);
                 of[pc[r]] = v[0];
@@ -691,12 +686,7 @@ __global__ __launch_bounds__(256) void frames_wave_kernel(const float* __restric
             const int2 d1 = ((const int2*)items)[4 * it + 2];
             const int type = d0.x, col = d0.y, i0 = d0.z, i1 = d0.w, i2 = d1.x, i3 = d1.y;
             V3 p0 = load_atom(xf, i0), p1 = load_atom(xf, i1), p2 = load_atom(xf, i2), p3 = load_atom(xf, i3);
-            if (has_align) {
-                p0 = rotate((p0 - c0) - dl, R);
-                p1 = rotate((p1 - c0) - dl, R);
-                p2 = rotate((p2 - c0) - dl, R);
-                p3 = rotate((p3 - c0) - dl, R);
-            }
+            if (has_align) align_item_atoms(type, p0, p1, p2, p3, c0, dl, R);
             float v[3];
             const int w = eval_item(type, p0, p1, p2, p3, v);
             of[col] = v[0];
@@ -727,6 +717,7 @@ struct RingArgs {
     int n_align, n_items, out_cols;
     int n_win;         // windows staged per frame (<= 64 ND)
     int n_slot, n_cons, n_load, depth;
+    int nt;            // loaders' gathers non-temporal
 };
 constexpr int RING_HEADER = 256;
 
@@ -748,12 +739,20 @@ __device__ __forceinline__ void ring_wait_frames(int k) { // at most k frames (N
 // LDS (wave-uniform address in M0) + 16 * lane.  Inline asm: hipcc picks the vaddr form for `base + offset[i]` (a 64-bit
 // vector add per instruction on the loader's issue path); M0 is written where it is read and restored.  The loader
 // counts these operations itself (vmcnt).
+// NT: non-temporal (the frame is read once: tools/micro/subline.hip moves whole 128-byte lines 12 % faster with it).
+template <bool NT>
 __device__ __forceinline__ void ring_dma16(const void* base_uniform, unsigned lane_off, unsigned lds_uniform) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(base_uniform), "s"(lds_uniform)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(base_uniform), "s"(lds_uniform)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(base_uniform), "s"(lds_uniform)
+                     : "memory");
 }
 typedef __attribute__((address_space(3))) volatile int* ring_word_t;
 __device__ __forceinline__ int ring_peek(ring_word_t w) { return __builtin_amdgcn_readfirstlane(*w); }
@@ -804,8 +803,13 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
                 const unsigned char* gsrc = (const unsigned char*)x + f * (long)a.frame_bytes;
                 unsigned char* slot = ring + (size_t)(n_issue % a.n_slot) * IMG_BYTES;
                 const unsigned slot_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)slot);
+                if (a.nt) {
 #pragma unroll
-                for (int i = 0; i < ND; ++i) ring_dma16(gsrc, goff[i], slot_lds + i * 1024);
+                    for (int i = 0; i < ND; ++i) ring_dma16<true>(gsrc, goff[i], slot_lds + i * 1024);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) ring_dma16<false>(gsrc, goff[i], slot_lds + i * 1024);
+                }
                 n_issue += a.n_load;
                 ++inflight;
             } else {
@@ -866,12 +870,7 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
         }
         float* of = out + f * (long)a.out_cols;
         auto item = [&](int type, int col, V3 p0, V3 p1, V3 p2, V3 p3) {
-            if (has_align) {
-                p0 = rotate((p0 - c0) - dl, R);
-                p1 = rotate((p1 - c0) - dl, R);
-                p2 = rotate((p2 - c0) - dl, R);
-                p3 = rotate((p3 - c0) - dl, R);
-            }
+            if (has_align) align_item_atoms(type, p0, p1, p2, p3, c0, dl, R);
             float v[3];
             const int w = eval_item(type, p0, p1, p2, p3, v);
             of[col] = v[0];
@@ -2244,9 +2243,10 @@ std::string jit_preamble(const JitSpec& j) {
         const char* e = diag_env("MOLANN_ELIDE_INVARIANT_ALIGNMENT");
         s += (e && e[0] == '1') ? "constexpr bool ELIDE_ALIGN = true;\n" : "constexpr bool ELIDE_ALIGN = false;\n";
     }
-    {   // cache policy of the x stream's LDS-DMA (gfx940+ CPol bits: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+    {   // cache policy of the x stream's LDS-DMA: 2 = nt, the default (every frame is read once; round 3: C2 39.5 -> 36.5 us,
+        // C3 66.4 -> 64.7 us per 1 M frames, tools/r03_ab.sh); experiments: 0 = default policy, 19 = sc0 sc1 nt
         const char* e = diag_env("MOLANN_DEBUG_DMA_AUX");
-        K("DMA_AUX", e ? atoi(e) : 0);
+        K("DMA_AUX", e ? atoi(e) : 2);
     }
     {
         std::vector<int> win = j.win.empty() ? std::vector<int>(1, 0) : j.win;
@@ -2267,7 +2267,7 @@ std::string jit_preamble(const JitSpec& j) {
     s += (debug_env().ablate & 512) ? "constexpr bool NO_STORES = true;\n" : "constexpr bool NO_STORES = false;\n";
     // diagnostic (bit 2048): consumers hand every tile back as soon as it is in registers and compute nothing
     s += (debug_env().ablate & 2048) ? "constexpr bool NO_COMPUTE = true;\n" : "constexpr bool NO_COMPUTE = false;\n";
-    s += diag_env("MOLANN_DEBUG_TILE_CONTIG") ? "constexpr bool TILE_CONTIG = true;\n" : "constexpr bool TILE_CONTIG = false;\n"; // experiment
+    { const char* e = diag_env("MOLANN_DEBUG_TILE_GROUP"); K("TILE_GROUP", e && atoi(e) > 0 ? atoi(e) : 1); } // adjacent tiles per block and turn (experiment)
     { const char* e = diag_env("MOLANN_DEBUG_ST_POLICY"); K("ST_POLICY", e ? atoi(e) : 1); } // cache policy of the output stores (1 = nt)
     { const char* e = diag_env("MOLANN_DEBUG_SLEEP"); K("SLEEP_N", e ? atoi(e) : 0); }
     { const char* e = diag_env("MOLANN_DEBUG_SPIN"); K("SPIN_N", e ? atoi(e) : 0); }   // with NO_COMPUTE: 64 x N v_fma per tile // with NO_COMPUTE: idle ~8k cycles x N per tile
@@ -2490,6 +2490,7 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
         ra.n_cons = std::max(1, std::min(14, ra.n_slot - 2 * ra.n_load));
         ra.depth = std::max(0, std::min(std::min(6, 63 / nd), (ra.n_slot - ra.n_cons) / ra.n_load - 1));
         if (debug_env().wave_bpc > 0) ra.n_cons = std::max(1, std::min(ra.n_cons, debug_env().wave_bpc)); // MOLANN_WAVE_BPC: experiment with fewer consumers
+        { const char* e = getenv("MOLANN_RING_NT"); ra.nt = e ? (e[0] == '1') : 1; }
         const int block = 64 * (ra.n_cons + ra.n_load);
         const size_t lds = (size_t)RING_HEADER + (size_t)ra.n_slot * img;
         const int grid = (int)std::min<long>(n_frames, p->num_cus);
@@ -3074,6 +3075,13 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
 
 int molann_plan_destroy(molann_plan* p) {
     if (!p) return MOLANN_OK;
+    {   // kernels of this plan may still be running or queued (`y = model(x); del model`): its code objects and device
+        // memory go only when the device has drained.  Destroying a plan is setup-time work, like creating one.
+        int cur = -1;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != p->device && hipSetDevice(p->device) == hipSuccess;
+        (void)hipDeviceSynchronize();
+        if (sw) (void)hipSetDevice(cur);
+    }
     if (p->jit_mod) (void)hipModuleUnload(p->jit_mod);
     if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
     if (p->mbwd_mod) (void)hipModuleUnload(p->mbwd_mod);

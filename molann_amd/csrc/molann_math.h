@@ -327,6 +327,23 @@ MOLANN_HD V3 rotate(V3 p, const float (&R)[9]) {
               fmaf(p.z, R[8], fmaf(p.y, R[5], p.x * R[2])));
 }
 
+// The atoms of one item as the feature sees them in the ALIGNED frame y = ((p - c0) - dl) R (ann.py:197, 565).  A position
+// item needs y itself.  Bond / angle / dihedral items are translation invariant: they are evaluated about the item's second
+// atom, y_k - y_1 = (p_k - p_1) R, so the short vectors between neighbouring atoms are formed from the INPUT coordinates
+// (exact up to the rounding of a vector of a few Angstrom) rather than from aligned coordinates that each carry the
+// rounding of their distance to the centroid - 1e-5 A at 100 A, which is what a 5000-atom frame's outer atoms have, and
+// what an ill-conditioned dihedral then amplifies.  Same values in exact arithmetic; used by the large-frame kernels.
+MOLANN_HD void align_item_atoms(int type, V3& p0, V3& p1, V3& p2, V3& p3, V3 c0, V3 dl, const float (&R)[9]) {
+    if (type == IT_POSITION) {
+        p0 = rotate((p0 - c0) - dl, R);
+        return;
+    }
+    p0 = rotate(p0 - p1, R);
+    p2 = rotate(p2 - p1, R);
+    p3 = rotate(p3 - p1, R);
+    p1 = v3(0.f, 0.f, 0.f);
+}
+
 // =================================================================================================
 // float64 instantiation of the forward (the reference follows x.dtype: `model.double()(x.double())`, ann.py:187-197,
 // 323-354).  Plain double arithmetic with libm - no fast approximations: the bar is 1e-10 against the reference's

@@ -75,6 +75,7 @@ struct Entry {
     std::vector<TensorKey> mlp_key;
     bool dirty = false; // molann::invalidate: repack at the next call whatever the keys say
     uint64_t last_use = 0;
+    int pins = 0;  // captured HIP graphs that launch through this plan (molann::pin): never evicted while > 0 (guarded by g_cache_mu)
     std::mutex mu; // update_* + launch of one plan are one critical section
     ~Entry() {
         if (plan) molann_plan_destroy(plan);
@@ -145,11 +146,14 @@ bool always_repack() {
 
 // caller holds g_cache_mu.  An evicted entry that a running call still holds lives until that call returns
 // (shared_ptr); its plan and device memory go with the last reference.
+// Entries pinned by a captured graph are not candidates: a graph replay never passes through entry_for (its
+// last_use does not move) and holds raw pointers into the plan's device memory and code objects.
 void evict_lru_locked() {
     while (g_cache.size() > cache_capacity()) {
-        auto victim = g_cache.begin();
+        auto victim = g_cache.end();
         for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
-            if (it->second->last_use < victim->second->last_use) victim = it;
+            if (it->second->pins == 0 && (victim == g_cache.end() || it->second->last_use < victim->second->last_use)) victim = it;
+        if (victim == g_cache.end()) return;   // everything left is pinned
         g_cache.erase(victim);
     }
 }
@@ -436,9 +440,29 @@ void invalidate(std::vector<int64_t> desc, int64_t device) {
     });
 }
 
-// the model is gone: give its plans (device blobs, workspaces, code objects) back
+// the model is gone: give its plans (device blobs, workspaces, code objects) back - except those a captured graph still
+// launches through (they go when the graph unpins them and the LRU gets to them)
 void release(std::vector<int64_t> desc, int64_t device) {
-    for_plans_of(desc, device, [](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) { return g_cache.erase(it); });
+    for_plans_of(desc, device, [](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) {
+        return it->second->pins > 0 ? ++it : g_cache.erase(it);
+    });
+}
+
+// A HIP graph captured through molann::run holds raw pointers to the plan's packed weights, reference and code objects:
+// the plans of this model stay in the cache while pinned.  Returns how many plans were pinned / unpinned.
+int64_t pin(std::vector<int64_t> desc, int64_t device) {
+    int64_t n = 0;
+    for_plans_of(desc, device, [&n](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) { ++it->second->pins; ++n; return ++it; });
+    return n;
+}
+int64_t unpin(std::vector<int64_t> desc, int64_t device) {
+    int64_t n = 0;
+    for_plans_of(desc, device, [&n](std::map<CacheKey, std::shared_ptr<Entry>>::iterator it) {
+        if (it->second->pins > 0) { --it->second->pins; ++n; }
+        return ++it;
+    });
+    { std::lock_guard<std::mutex> lock(g_cache_mu); evict_lru_locked(); }
+    return n;
 }
 
 int64_t drop_plans() {
@@ -645,6 +669,8 @@ TORCH_LIBRARY(molann, m) {
     m.def("launch_info(int[] desc, int device) -> str", launch_info);
     m.def("invalidate(int[] desc, int device) -> ()", invalidate);
     m.def("release(int[] desc, int device) -> ()", release);
+    m.def("pin(int[] desc, int device) -> int", pin);
+    m.def("unpin(int[] desc, int device) -> int", unpin);
     m.def("drop_plans() -> int", drop_plans);
     m.def("cached_plans() -> int", cached_plans);
 }

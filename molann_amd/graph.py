@@ -14,6 +14,13 @@ Weights are packed into the plan before capture; call `g.recapture()` after chan
 import torch
 
 
+def _unpin_plans(desc, device):
+    try:
+        torch.ops.molann.unpin(desc, device)
+    except Exception:   # interpreter shutdown / library gone
+        pass
+
+
 class GraphedForward(object):
     def __init__(self, model, example_x, warmup=3):
         assert example_x.is_cuda and example_x.dtype == torch.float32
@@ -35,7 +42,22 @@ class GraphedForward(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_y = self.model(self.static_x)
+        self._pin()
         return self
+
+    def _pin(self):
+        """The captured launches hold raw pointers into the plan (packed weights, reference, code objects).  A plan the
+        module owns (ctypes) lives as long as `self.model`; a MolANN served by the dispatcher operator has its plan in that
+        library's LRU cache, which a replay never touches: pin it there for the life of this graph."""
+        import weakref
+        old = self.__dict__.pop("_unpin", None)
+        if old is not None:
+            old()
+        st = getattr(self.model, "__dict__", {}).get("_fast")
+        if st is not None and st.get("fused") and st.get("op") is not None:
+            desc, dev = list(st["desc"]), self.static_x.device.index
+            torch.ops.molann.pin(desc, dev)
+            self._unpin = weakref.finalize(self, _unpin_plans, desc, dev)
 
     def __call__(self, x):
         if x.shape != self.static_x.shape:
@@ -65,6 +87,10 @@ class GraphedForces(GraphedForward):
         plan = self.model.plan_for(x) if hasattr(self.model, "plan_for") else None
         if plan is None or not plan.supports_backward():
             raise NotImplementedError("GraphedForces needs a model served by one fused plan with a backward kernel")
+        if plan.backward_kind() != 2:
+            # the three-launch backward orders its shared workspace with plan-owned events and a side stream: not capturable
+            raise NotImplementedError("GraphedForces needs the one-pass backward kernel (molann_plan_backward_kind == 2); this plan's "
+                                      "backward is the three-launch path")
         self._plan = plan
         self.static_dy = torch.zeros_like(self.static_y)
         self.static_dx = torch.empty_like(x)

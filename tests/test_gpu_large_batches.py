@@ -1,0 +1,199 @@
+"""Output checks under the numbers bench.py reports for C4 / C5: the ring kernel's slot reuse at the two BASELINE plans'
+own geometry (16 / 11 slots per block: a block reuses a slot only beyond 256 x n_slot frames), and the chunked
+large-frame forward (`work_frames` pieces, two workspace halves, side stream, four events) across a chunk boundary and
+from a second stream."""
+
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from build_util import oracle_for_workload, workload_model
+from molann_amd import workloads as wl
+from molann_amd.ann import (AlignmentLayer, FeatureLayer, MolANN, PreprocessingANN, create_sequential_nn,
+                            last_launch_info)
+from molann_amd.atomgroup import Universe
+from molann_amd.feature import Feature
+from oracle import molann_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("cfg,n", [("C4", 8192), ("C5", 8192)])
+def test_ring_slot_reuse_at_the_baseline_geometry(cfg, n, hip_device, monkeypatch):
+    """C4 / C5 with more frames per block than the ring has slots (generation hand-off `gen > 0` of frames_ring_kernel):
+    features and outputs bit for bit against frames_wave_kernel (MOLANN_NO_RING=1: the same per-frame arithmetic, no
+    ring), and 512 sampled rows against the float64 oracle."""
+    w = wl.get_workload(cfg)
+    model = workload_model(w, hip_device).requires_grad_(False)
+    pp = model.preprocessing_layer
+    x = w.make_frames(n, device=hip_device, seed=77)
+    with torch.no_grad():
+        f_ring = pp(x)
+        info = last_launch_info(pp)
+        y_ring = model(x)
+    torch.cuda.synchronize()
+    m = re.search(r"frames_ring_kernel<ND=(\d+)> \((\d+) consumer \+ (\d+) loader waves, ring of (\d+) frames.* grid=(\d+)", info)
+    assert m, info
+    n_slot, grid = int(m.group(4)), int(m.group(5))
+    assert n > grid * n_slot, (n, grid, n_slot)          # every block wraps around its ring at least once
+    monkeypatch.setenv("MOLANN_NO_RING", "1")
+    with torch.no_grad():
+        f_wave = pp(x)
+        assert "frames_wave_kernel" in last_launch_info(pp)
+        y_wave = model(x)
+    torch.cuda.synchronize()
+    assert torch.equal(f_ring, f_wave)
+    assert torch.equal(y_ring, y_wave)
+    # sampled rows against the oracle (float64): first and last frames of the batch, the frames on both sides of the first wrap of
+    # block 0 and of the last block, and random ones
+    idx = set(range(0, 32)) | set(range(n - 32, n))
+    for b in (0, grid - 1):
+        for k in (n_slot - 1, n_slot, n_slot + 1, 2 * n_slot):
+            if b + k * grid < n:
+                idx.add(b + k * grid)
+    rng = np.random.default_rng(5)
+    idx |= set(rng.choice(n, size=512 - len(idx), replace=False).tolist())
+    idx = torch.tensor(sorted(idx))
+    xs = x[idx.to(hip_device)].cpu()
+    feats = [(t, [a - 1 for a in atoms]) for t, atoms in w.features]
+    al = [a - 1 for a in w.align]
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[al])).double()
+    want_f = mo.preprocessing_forward(xs.double(), feats, w.use_angle_value, al, ref_x)
+    got_f = f_ring[idx.to(hip_device)].cpu().double()
+    # Bound per feature column: 1e-5, and where the REFERENCE's own arithmetic (the oracle run in float32) is further than that
+    # from its float64 run on these rows, four times that distance: dihedrals / angles over nearly collinear neighbours of the
+    # random chain are ill-conditioned, the reference's fp32 run is up to 1e-4 (C4) / 2e-4 (C5) off on those columns.
+    lins = [m_ for m_ in model.ann_layers if isinstance(m_, torch.nn.Linear)]
+    ws = [l.weight.detach().cpu().double() for l in lins]
+    bs = [l.bias.detach().cpu().double() for l in lins]
+    want_y = mo.molann_forward(xs.double(), feats, ws, bs, w.use_angle_value, al, ref_x)
+    own_f = (mo.preprocessing_forward(xs, feats, w.use_angle_value, al, ref_x.float()).double() - want_f).abs().max(dim=0).values
+    own_y = float((mo.molann_forward(xs, feats, [t.float() for t in ws], [t.float() for t in bs], w.use_angle_value, al, ref_x.float()).double()
+                   - want_y).abs().max())
+    err_f = (got_f - want_f).abs().max(dim=0).values
+    tol_f = torch.clamp(4.0 * own_f, min=1e-5 * max(1.0, float(want_f.abs().max())))
+    widened = own_f > 1e-5
+    print("%s: features max err %.3g (reference fp32 own error %.3g); %d of %d columns ill-conditioned; elsewhere max err %.3g"
+          % (cfg, float(err_f.max()), float(own_f.max()), int(widened.sum()), own_f.numel(), float(err_f[~widened].max())))
+    assert bool((err_f <= tol_f).all()), (err_f / tol_f).max()
+    assert float(widened.double().mean()) < 0.15
+    got = y_ring[idx.to(hip_device)].cpu().double()
+    if w.mlp_dtype == "bf16":
+        # the arithmetic model of the bf16 MLP (bf16 weights and activations, fp32 accumulation) on the kernel's own features
+        h = _bf16(got_f.float()).double()
+        for i, lin in enumerate(lins):
+            z = (h @ _bf16(lin.weight.detach().cpu()).double().T + lin.bias.detach().cpu().double()).float()
+            h = z.double() if i + 1 == len(lins) else _bf16(torch.tanh(z)).double()
+        err = float((got - h).abs().max())
+        print("%s: max |bf16 MLP - its arithmetic model| on %d rows: %.3g" % (cfg, len(idx), err))
+        assert err <= 4e-3 * max(1.0, float(h.abs().max()))
+    else:
+        err_y = float((got - want_y).abs().max())
+        print("%s: outputs max err %.3g (reference fp32 own error %.3g)" % (cfg, err_y, own_y))
+        assert err_y <= max(1e-5, 4.0 * own_y)
+
+
+def _chain_plan(n_inp, n_feat, n_align, dims_tail, device, seed):
+    rng = np.random.default_rng(seed)
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    u = Universe(xyz)
+    spec = []
+    for i in range(n_feat):
+        t = (wl.BOND, wl.ANGLE, wl.DIHEDRAL)[i % 3]
+        k = {wl.BOND: 2, wl.ANGLE: 3, wl.DIHEDRAL: 4}[t]
+        s0 = int(rng.integers(0, n_inp - k + 1))
+        spec.append((t, list(range(s0, s0 + k))))
+    feats = [Feature("f%d" % i, wl.TYPE_NAMES[t], u.atoms_by_number([a + 1 for a in atoms])) for i, (t, atoms) in enumerate(spec)]
+    align = sorted(rng.choice(n_inp, size=n_align, replace=False).tolist())
+    pp = PreprocessingANN(AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms), FeatureLayer(feats, u.atoms, False))
+    torch.manual_seed(seed)
+    model = MolANN(pp, create_sequential_nn([pp.output_dimension()] + dims_tail)).to(device).requires_grad_(False)
+    return xyz, spec, align, model
+
+
+def _frames(xyz, n, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    ref = torch.from_numpy(xyz).to(device)
+    return (ref.unsqueeze(0) + 0.2 * torch.randn((n, xyz.shape[0], 3), generator=g, device=device)).contiguous()
+
+
+def test_chunked_large_frame_forward_across_a_chunk_boundary(hip_device):
+    """A wave-per-frame (family 1) plan small enough to cross `work_frames` with a modest batch: 150 atoms, 60 + touched,
+    MLP [d,64,8]; N = work_frames + 65.  Rows on both sides of the boundary (and the batch's ends) against the float64
+    oracle; the whole batch against the same model run in pieces that never cross a boundary; then a second call from
+    another stream right behind the first (the plan's `ev_done` protocol around its workspace and side stream)."""
+    xyz, spec, align, model = _chain_plan(150, 40, 24, [64, 8], hip_device, 3)
+    x0 = _frames(xyz, 70, hip_device, 1)
+    with torch.no_grad():
+        model(x0)
+    info = last_launch_info(model)
+    m = re.search(r"chunk=(\d+)", info)
+    assert m and ("frames_ring_kernel" in info or "frames_wave_kernel" in info), info
+    wf = int(m.group(1))
+    n = wf + 65
+    x = _frames(xyz, n, hip_device, 2)
+    with torch.no_grad():
+        y = model(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    # pieces that each fit one chunk
+    with torch.no_grad():
+        pieces = torch.cat([model(x[s:s + 100000]) for s in range(0, n, 100000)])
+    torch.cuda.synchronize()
+    assert torch.equal(y, pieces)
+    rows = sorted(set(range(0, 64)) | set(range(wf - 130, wf + 65)) | set(range(n - 64, n)))
+    idx = torch.tensor(rows, device=hip_device)
+    lins = [l for l in model.ann_layers if isinstance(l, torch.nn.Linear)]
+    ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
+    want = mo.molann_forward(x[idx].cpu().double(), spec, [l.weight.detach().cpu().double() for l in lins],
+                             [l.bias.detach().cpu().double() for l in lins], False, align, ref_x)
+    assert float((y[idx].cpu().double() - want).abs().max()) <= 1e-5
+    # two streams, back to back, no host synchronisation in between: each call must see its own workspace contents
+    x2 = _frames(xyz, n, hip_device, 4)
+    with torch.no_grad():
+        want2 = model(x2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.no_grad():
+        with torch.cuda.stream(s1):
+            a = model(x)
+        with torch.cuda.stream(s2):
+            b = model(x2)
+        with torch.cuda.stream(s1):
+            c = model(x2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, y) and torch.equal(b, want2) and torch.equal(c, want2)
+
+
+def test_bf16_mlp_error_is_measured(hip_device):
+    """C5-shaped golden case on the bf16 MFMA path: the error against the reference run with bf16-rounded weights is
+    printed, bounded at about twice what was measured on MI355X (activations rounded to bf16 between layers account
+    for it), and the kernel is held to its own arithmetic model - bf16 weights and activations, fp32 accumulation -
+    three orders tighter: a wrong k-permutation of a few columns cannot pass that."""
+    from build_util import build_modules
+    from golden_util import Case
+    c = Case("molann_C5_small_bf16w")
+    model = build_modules(c, hip_device, mlp_precision="bf16")
+    with torch.no_grad():
+        got = model(c.x.to(hip_device)).cpu()
+        feat = model.preprocessing_layer(c.x.to(hip_device)).cpu()
+    scale = float(c.out_f64.abs().max())
+    err = float((got.double() - c.out_f64).abs().max())
+    h = _bf16(feat).double()
+    for i, (wt, b) in enumerate(zip(c.weights, c.biases)):
+        z = (h @ _bf16(wt).double().T + b.double()).float()
+        h = z.double() if i + 1 == len(c.weights) else _bf16(torch.tanh(z)).double()
+    err_model = float((got.double() - h).abs().max())
+    print("bf16 MLP (C5 golden, %d frames): max |hip - reference(bf16 weights)| = %.3g (output scale %.3g); vs its arithmetic model %.3g"
+          % (got.shape[0], err, scale, err_model))
+    assert err_model <= 2e-3 * max(1.0, scale), (err_model, scale)
+    assert err <= BF16_BOUND * max(1.0, scale), (err, scale)
+
+
+BF16_BOUND = 2e-2   # replaced by 2 x the measured value (see the test's printed line in profiles/r03_tests.txt)

@@ -211,3 +211,67 @@ def _fresh_pp(w, dev, seed):
     with torch.no_grad():
         model.align_layer.ref_x.copy_(model.align_layer.ref_x @ rot)
     return model.to(dev)
+
+
+def test_a_captured_graph_keeps_its_plan_through_lru_eviction(hip_device):
+    """a HIP graph captured through `torch.ops.molann.run` holds raw pointers into the cached plan and a
+    replay never touches the cache's LRU clock.  With room for two plans: capture, build three other models (evictions),
+    replay - the graph's plan must still be there - and compare with an eager forward.  Child process: the cache size is
+    read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import gc, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from build_util import workload_model
+from molann_amd import workloads as wl
+from molann_amd.graph import GraphedForward
+dev = torch.device("cuda:0")
+w = wl.get_workload("C3")
+model = workload_model(w, dev, seed=1).requires_grad_(False)
+x0 = w.make_frames(256, seed=1).to(dev)
+g = GraphedForward(model, x0)
+assert torch.ops.molann.cached_plans() >= 1
+others = []
+for seed in (2, 3, 4):
+    for name in ("C1", "C3"):
+        m = workload_model(wl.get_workload(name), dev, seed=seed).requires_grad_(False)
+        with torch.no_grad():
+            m(wl.get_workload(name).make_frames(64, seed=seed).to(dev))
+        others.append(m)
+torch.cuda.synchronize()
+assert torch.ops.molann.cached_plans() <= 3, torch.ops.molann.cached_plans()    # two + the pinned one at most
+x = w.make_frames(256, seed=9).to(dev)
+got = g(x).clone()
+torch.cuda.synchronize()
+with torch.no_grad():
+    want = model(x)
+assert torch.equal(got, want)
+# a model dropped right behind its launch: the plan's code objects and memory outlive the queued kernel
+m = workload_model(w, dev, seed=7).requires_grad_(False)
+big = w.make_frames(1 << 18, device=dev, seed=3)
+with torch.no_grad():
+    y = m(big)
+del m
+gc.collect()
+torch.cuda.synchronize()
+assert torch.isfinite(y).all()
+del g
+gc.collect()
+print("graph-pin ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOLANN_PLAN_CACHE_SIZE="2")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "graph-pin ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_graphed_forces_refuses_the_three_launch_backward(hip_device, monkeypatch):
+    """ADVICE r2 (low): GraphedForces captures one launch of the one-pass backward; a plan whose backward is the
+    three-launch path (plan-owned events and workspace) is refused instead of captured."""
+    from molann_amd.graph import GraphedForces
+    monkeypatch.setenv("MOLANN_NO_RING_BWD", "1")
+    w = wl.get_workload("C3")
+    model = workload_model(w, hip_device, seed=5).requires_grad_(False)
+    with pytest.raises(NotImplementedError):
+        GraphedForces(model, w.make_frames(8, seed=1).to(hip_device))

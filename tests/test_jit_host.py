@@ -7,27 +7,7 @@ import pytest
 from molann_amd import _capi, workloads as wl
 
 
-def _desc(w):
-    d = _capi.PlanDesc()
-    d.abi_version, d.n_inp = _capi.ABI_VERSION, w.n_atoms
-    keep = []
-    I = lambda v: (ctypes.c_int32 * max(1, len(v)))(*v)  # noqa: E731
-    if w.align:
-        a, r = I([x - 1 for x in w.align]), (ctypes.c_float * (3 * len(w.align)))()
-        d.n_align, d.align_idx, d.ref_x = len(w.align), a, r
-        keep += [a, r]
-    ptr, flat = [0], []
-    for _, atoms in w.features:
-        flat += [x - 1 for x in atoms]
-        ptr.append(len(flat))
-    ft, fp, fi = I([t for t, _ in w.features]), I(ptr), I(flat)
-    d.n_features, d.feat_type, d.feat_ptr, d.feat_idx = len(w.features), ft, fp, fi
-    keep += [ft, fp, fi]
-    if w.mlp_dims:
-        ld = I(w.mlp_dims)
-        d.n_layers, d.layer_dims = len(w.mlp_dims) - 1, ld
-        keep.append(ld)
-    return d, keep
+_desc = _capi.workload_desc
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C3p"])
