@@ -192,8 +192,8 @@ def test_bf16_mlp_error_is_measured(hip_device):
     err_model = float((got.double() - h).abs().max())
     print("bf16 MLP (C5 golden, %d frames): max |hip - reference(bf16 weights)| = %.3g (output scale %.3g); vs its arithmetic model %.3g"
           % (got.shape[0], err, scale, err_model))
-    assert err_model <= 2e-3 * max(1.0, scale), (err_model, scale)
+    assert err_model <= 5e-4 * max(1.0, scale), (err_model, scale)   # (an activation on a bf16 rounding boundary may flip by one ulp)
     assert err <= BF16_BOUND * max(1.0, scale), (err, scale)
 
 
-BF16_BOUND = 2e-2   # replaced by 2 x the measured value (see the test's printed line in profiles/r03_tests.txt)
+BF16_BOUND = 2.5e-3   # measured on MI355X (round 3): 1.18e-3 at output scale 0.35, and 4.5e-8 against the arithmetic model

@@ -48,7 +48,8 @@ def test_bf16_mlp_case(hip_device):
     got = _run(model, c.x.to(hip_device))
     scale = float(c.out_f64.abs().max())
     err = float((got.double() - c.out_f64).abs().max())
-    assert err <= 2e-2 * max(1.0, scale), (err, scale)   # bf16 activations: 8-bit mantissa through 3 layers
+    # measured 1.18e-3 (output scale 0.35): twice that; tests/test_gpu_large_batches.py holds the kernel to its arithmetic model
+    assert err <= 2.5e-3 * max(1.0, scale), (err, scale)   # bf16 activations: 8-bit mantissa through 3 layers
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 63, 64, 65, 127, 128, 129, 1000, 4099])
