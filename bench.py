@@ -11,8 +11,9 @@ other configs) are selectable.  Inputs rotate over several distinct buffers (> 1
 
 N > 1: one process per GPU over RCCL.  Either the driver starts the ranks (torch.distributed.run sets
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or `python bench.py --gpus N` run plainly starts them itself:
-the parent counts the devices WITHOUT initialising the GPU, spawns N children with that environment and
-exits with their status (it never touches the GPU, and a rank that fails takes the run down, non-zero).
+the parent counts the devices in sysfs (KFD topology, narrowed by *_VISIBLE_DEVICES: no HIP call, /dev/kfd never opened),
+spawns N children with that environment, each pinned to its own slice of the host's cores, and exits with their status
+(a rank that fails takes the run down, non-zero).
 Frames are sharded, every rank runs the same K steps on its own shard (weak scaling, no data-path
 collective) and ONE all-gather of the last step's output shards closes the timed region (BASELINE.json:
 "RCCL all-gather of outputs ... only at the end").  That gather either follows the last step as one
@@ -103,22 +104,64 @@ def check_env(args, environ=None):
     return env, bool(bad)
 
 
-def gpu_clocks(index):
-    """Current / maximum shader and memory clocks from sysfs where readable (None otherwise)."""
-    out = {}
-    try:
-        import glob
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if index < len(cards):
-            base = os.path.dirname(cards[index])
-            for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
-                lines = open(os.path.join(base, fn)).read().split("\n")
-                levels = [ln.split(":", 1)[1].strip() for ln in lines if ":" in ln]
-                cur = [ln.split(":", 1)[1].replace("*", "").strip() for ln in lines if ln.strip().endswith("*")]
-                out[key] = {"current": cur[0] if cur else None, "levels": levels}
-    except Exception:
-        pass
-    return out or None
+def _kfd_gpu_nodes(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPU nodes of the KFD topology (a node with SIMDs is a GPU, one without is a CPU), in node order; None if the
+    topology is not readable.  Reading sysfs opens no device file."""
+    import glob
+    nodes = []
+    paths = sorted(glob.glob(os.path.join(root, "*", "properties")), key=lambda q: int(os.path.basename(os.path.dirname(q))))
+    if not paths:
+        return None
+    for q in paths:
+        try:
+            props = dict(ln.split(None, 1) for ln in open(q).read().splitlines() if " " in ln)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            nodes.append(props)
+    return nodes
+
+
+def visible_gpu_count(environ=None, root="/sys/class/kfd/kfd/topology/nodes"):
+    """How many GPUs a rank started from this environment will see, WITHOUT a HIP / HSA call in this process: the KFD
+    topology in sysfs, narrowed by ROCR_VISIBLE_DEVICES and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (each a
+    comma-separated list of indices into the previous view, or GPU-<uuid> names; the list ends at the first invalid
+    entry, as the runtimes read it).  Where sysfs is not there the count comes from a CHILD process."""
+    environ = os.environ if environ is None else environ
+    nodes = _kfd_gpu_nodes(root)
+    if nodes is None:
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                                 text=True, timeout=300, env=dict(environ))
+            return int(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            return 0
+    view = ["%x" % int(p.get("unique_id", "0")) for p in nodes]
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = environ.get(var)
+        if val is None:
+            continue
+        if var == "CUDA_VISIBLE_DEVICES" and environ.get("HIP_VISIBLE_DEVICES") is not None:
+            continue
+        picked = []
+        for tok in [t.strip() for t in val.split(",")]:
+            if tok.isdigit() and int(tok) < len(view):
+                picked.append(view[int(tok)])
+            elif tok.upper().startswith("GPU-") and tok[4:].lower().lstrip("0") in [v.lstrip("0") for v in view]:
+                picked.append(tok[4:].lower())
+            else:
+                break
+        view = picked
+    return len(view)
+
+
+def cpu_slice(rank, n_ranks, cores=None):
+    """The contiguous share of this process's allowed cores that rank `rank` of `n_ranks` pins itself to."""
+    cores = sorted(os.sched_getaffinity(0)) if cores is None else sorted(cores)
+    per = len(cores) // max(1, n_ranks)
+    if per < 1:
+        return cores
+    return cores[rank * per:(rank + 1) * per]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -136,7 +179,7 @@ def _free_port():
 def launch_ranks(n, argv, device_count=None, popen=subprocess.Popen):
     """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment) and
     return the exit status of the run: 0 only if every rank returned 0.  The caller has made no GPU call."""
-    have = torch.cuda.device_count() if device_count is None else device_count   # does not initialise the GPU
+    have = visible_gpu_count() if device_count is None else device_count   # sysfs: no HIP / HSA call, no /dev/kfd in this process
     if have < n:
         sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); not running a smaller job under "
                          "that name\n" % (n, have))
@@ -145,7 +188,8 @@ def launch_ranks(n, argv, device_count=None, popen=subprocess.Popen):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MOLANN_BENCH_CPU_SLICE=",".join(str(c) for c in cpu_slice(r, n)))
         procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     status, live = 0, list(procs)
     while live:
@@ -300,6 +344,13 @@ def cpu_baseline(w, model, seconds):
 # one rank
 # ------------------------------------------------------------------------------------------------------
 
+def kernel_names(info):
+    """The kernels of a launch-info string with their template arguments, without the launch geometry: what identifies the code
+    that ran ('molann_lane_jit<NL=2>', 'frames_ring_kernel<ND=8> || molann_mlp_chain<f32,FB=4>')."""
+    import re
+    return " || ".join(m.group(0) for m in re.finditer(r"\b(?:molann_|frames_|mlp_)\w+(?:<[^>]*>)?", info or ""))
+
+
 def pick_buffers(args, buf_bytes):
     nbuf = args.buffers if args.buffers > 0 else max(2, min(8, -(-(5 << 28) // max(1, buf_bytes))))  # > 1.25 GiB in total
     if buf_bytes > (8 << 30) and args.buffers <= 0:
@@ -389,10 +440,6 @@ def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, e
             side.wait_mark(b)
             per.append(side.ms_between(a, b))
         per.sort()
-        # shader / memory clock while the kernel runs (sysfs, where readable): read with launches in flight
-        for i in range(60):
-            model(xs[i % nbuf])
-        clocks = gpu_clocks(getattr(side, "index", 0))
         side.sync()
         if kernel_ms is None:       # --steps 1 with the gather: no plain step inside the timed region
             kernel_ms = per[len(per) // 2]
@@ -416,8 +463,10 @@ def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, e
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
+                # counters taken on another kernel (or another launch size) say nothing about this run: the figure is quoted only
+                # when the kernel that ran is the one the PMC passes profiled
                 t = json.load(open(tfile)).get(w.name, {})
-                if t.get("frames_per_launch") in (None, frames):
+                if t.get("frames_per_launch") in (None, frames) and kernel_names(side.kernels(model)) == kernel_names(t.get("kernels", "")):
                     traffic = t.get("bytes_per_launch")
             except Exception:
                 traffic = None
@@ -436,8 +485,8 @@ def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, e
                        "env": env if env is not None else molann_env(),
                        "dist": {"world_size": dist.get_world_size() if distributed else 1,
                                 "backend": dist.get_backend() if distributed else None,
-                                "devices": devices, "launched_by": os.environ.get("MOLANN_BENCH_LAUNCHER", "self" if not distributed else "external")},
-                       "clocks_under_load": clocks},
+                                "devices": devices, "launched_by": os.environ.get("MOLANN_BENCH_LAUNCHER", "self" if not distributed else "external"),
+                                "cpu_affinity": sorted(os.sched_getaffinity(0))}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_frame": alg_bytes, "dense_bytes_per_frame": dense_bytes,
@@ -481,6 +530,11 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("MOLANN_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL calls on one rank
+    if os.environ.get("MOLANN_BENCH_CPU_SLICE"):      # the launcher's share of the host cores for this rank
+        try:
+            os.sched_setaffinity(0, {int(c) for c in os.environ["MOLANN_BENCH_CPU_SLICE"].split(",")})
+        except (OSError, ValueError):
+            pass
     side = HipSide(local_rank)
     if distributed:
         side.init_process_group()

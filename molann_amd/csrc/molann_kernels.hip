@@ -889,6 +889,8 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
     }
 }
 
+#include "molann_align_ring.inc"
+
 // =============================================================================================
 // float64 path: the same forward for `model.double()(x.double())` (the reference follows x.dtype, ann.py:187-197)
 // =============================================================================================
@@ -2509,6 +2511,32 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
 #undef LAUNCH_RING
         snprintf(p->last_info, sizeof(p->last_info), "frames_ring_kernel<ND=%d> (%d consumer + %d loader waves, ring of %d frames, %d windows) grid=%d block=%d lds=%zu",
                  nd, ra.n_cons, ra.n_load, ra.n_slot, p->ring_nwin, grid, block, lds);
+    } else if (mode == 1 && getenv("MOLANN_NO_RING") == nullptr && 12l * p->n_inp <= (163840 - ALIGN_RING_HEADER) / 2 - 1024) {
+        // AlignmentLayer.forward on large frames: the dense frame staged once in an LDS ring, groups of consumer waves
+        // per frame (frames_align_ring_kernel, molann_align_ring.inc)
+        AlignRingArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.n_frames = n_frames; ra.n_inp = p->n_inp; ra.n_align = p->n_align;
+        ra.frame_bytes = 12 * p->n_inp;
+        ra.n_chunks = ra.frame_bytes / 16;
+        ra.tail_dw = (ra.frame_bytes % 16) / 4;
+        const int dma_kib = ra.n_chunks / 64 + ((ra.n_chunks % 64) ? 1 : 0);
+        ra.slot_bytes = ceil_to(std::max(dma_kib * 1024, ra.n_chunks * 16 + 16), 1024);
+        ra.n_slot = std::min(16, (163840 - ALIGN_RING_HEADER) / ra.slot_bytes);
+        ra.n_load = ra.frame_bytes >= 16384 ? 2 : 4;
+        ra.n_group = std::max(1, std::min(12, ra.n_slot - ra.n_load));
+        ra.group_waves = std::max(1, 8 / ra.n_group);
+        ra.n_cons = ra.n_group * ra.group_waves;
+        ra.out_wide = (a.out_wide && (ra.frame_bytes % 16) == 0) ? 1 : 0;
+        { const char* e = getenv("MOLANN_RING_NT"); ra.nt = e ? (e[0] == '1') : 1; }
+        const int block = 64 * (ra.n_cons + ra.n_load);
+        const size_t lds = (size_t)ALIGN_RING_HEADER + (size_t)ra.n_slot * ra.slot_bytes;
+        const int grid = (int)std::min<long>(n_frames, p->num_cus);
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)frames_align_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr_done = true; }
+        hipLaunchKernelGGL(frames_align_ring_kernel, dim3(grid), dim3(block), lds, stream, x, out, p->d_align_idx, p->d_ref, p->d_ref64, ra);
+        snprintf(p->last_info, sizeof(p->last_info), "frames_align_ring_kernel (%d groups x %d consumer waves + %d loader waves, ring of %d frames of %d bytes) grid=%d block=%d lds=%zu",
+                 ra.n_group, ra.group_waves, ra.n_load, ra.n_slot, ra.slot_bytes, grid, block, lds);
     } else {
         const int wpb = 4;
         // blocks per CU: all wave slots.  (The gather is HBM-latency bound and wants every wave it can get; the MLP

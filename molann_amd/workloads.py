@@ -203,7 +203,13 @@ def _a3():
                     description="22 atoms, AlignmentLayer.forward alone (Kabsch on 7 backbone atoms, all 22 atoms written back)")
 
 
-_FACTORIES = {"A3": _a3, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
+def _a4():
+    xyz = synthetic_chain()
+    return Workload("A4", xyz, [], align=tuple(range(9, 5001, 16)), frames=1 << 18, rigid_motion=True, kind="align",
+                    description="5000-atom chain, AlignmentLayer.forward alone (Kabsch on 312 'CA', all 5000 atoms written back)")
+
+
+_FACTORIES = {"A3": _a3, "A4": _a4, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
 
 
 def get_workload(name):

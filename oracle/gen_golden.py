@@ -376,7 +376,31 @@ def main():
     print(json.dumps(meta, indent=1))
 
 
+def round3_main():
+    """Round 3 additions only (the other files are left untouched): AlignmentLayer.forward on large frames - the 5000-atom
+    chain of workload A4 (x regenerated from the seed) and a 301-atom chain whose frame is not a multiple of 16 bytes - and
+    a MolANN with hidden widths 33..64 on the 22-atom system."""
+    os.makedirs(OUT, exist_ok=True)
+    w = wl.get_workload("A4")
+    uc = Universe(w.ref_xyz)
+    allc = list(range(1, w.n_atoms + 1))
+    run_case("align_chain5000", uc, w.make_frames(8, seed=w.seed), allc, align=list(w.align), kind="align",
+             x_recipe={"workload": "A4", "frames": 8, "seed": w.seed})
+    xyz301 = w.ref_xyz[:301] - w.ref_xyz[:301].mean(axis=0, keepdims=True)
+    u301 = Universe(xyz301)
+    run_case("align_chain301", u301, noisy(xyz301, 70, 0.1, 301, rigid=True), list(range(1, 302)), align=list(range(3, 302, 7)),
+             kind="align", extra={"ref_xyz": xyz301})
+    pdb = read_pdb_xyz("/root/reference/test/alanine-dipeptide-vacuum.pdb")
+    u = Universe(pdb)
+    w3 = wl.get_workload("C3")
+    run_case("molann_C3_wide64", u, w3.make_frames(512, seed=64), list(range(1, 23)), w3.features, align=w3.align, mlp_dims=[6, 64, 64, 8])
+    run_case("molann_C3_wide48", u, w3.make_frames(300, seed=48), list(range(1, 23)), w3.features, align=w3.align, mlp_dims=[6, 48, 33, 5])
+
+
 if __name__ == "__main__":
+    if "--round3" in sys.argv:
+        round3_main()
+        sys.exit(0)
     if "--grads" in sys.argv:
         grad_main()
     else:

@@ -13,6 +13,8 @@ _chain = {}
 
 
 def universe_for(case):
+    if getattr(case, "ref_xyz", None) is not None:
+        return Universe(case.ref_xyz)
     top = max(case.input_ix) + 1
     if top <= 22:
         return Universe(wl.ALA_DIPEPTIDE_XYZ)

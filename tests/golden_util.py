@@ -30,6 +30,7 @@ class Case(object):
         self.n_inp = int(d["n_inp"])
         self.input_ix = d["input_ix"].tolist()
         self.use_angle_value = bool(d["use_angle_value"])
+        self.ref_xyz = d["ref_xyz"] if "ref_xyz" in d else None      # a system of its own (neither the PDB nor the 5000-atom chain)
         self.out_f32 = torch.from_numpy(d["out_f32"])
         self.out_f64 = torch.from_numpy(d["out_f64"])
         if "x" in d:

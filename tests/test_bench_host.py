@@ -141,7 +141,7 @@ def test_rank_code_at_world_size_2_over_gloo(mode):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["final_allgather"] is True
     assert d["config"]["dist"] == {"world_size": 2, "backend": "gloo", "devices": ["cpu (oracle stand-in)"] * 2,
-                                   "launched_by": d["config"]["dist"]["launched_by"]}
+                                   "launched_by": d["config"]["dist"]["launched_by"], "cpu_affinity": d["config"]["dist"]["cpu_affinity"]}
     assert abs(d["value"] - 203 * 2 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
     ph = d["phases"]
     assert ph["allgather_mode"] in ("collective", "overlap") and (mode == "auto" or ph["allgather_mode"] == mode)
@@ -150,3 +150,49 @@ def test_rank_code_at_world_size_2_over_gloo(mode):
     if mode == "auto":
         assert set(ph["allgather_warmup_ms"]) == {"collective", "overlap"}
     assert "cpu_baseline" not in d
+
+
+def _fake_kfd(tmp_path, gpus=4):
+    root = tmp_path / "nodes"
+    for i in range(gpus + 1):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        simd = 0 if i == 0 else 1024        # node 0: the CPU
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nunique_id %d\ngfx_target_version %d\n"
+                                      % (64 if i == 0 else 0, simd, 0 if i == 0 else 0xabc0 + i, 0 if i == 0 else 90500))
+    return str(root)
+
+
+def test_device_count_comes_from_sysfs_and_honours_visibility(tmp_path):
+    """the launcher counts GPUs from the KFD topology in sysfs (no HIP call in the parent), narrowed by
+    ROCR_VISIBLE_DEVICES, then HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES when HIP_ is absent)."""
+    root = _fake_kfd(tmp_path, gpus=4)
+    assert bench.visible_gpu_count({}, root) == 4
+    assert bench.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,2"}, root) == 2
+    assert bench.visible_gpu_count({"HIP_VISIBLE_DEVICES": "1,7,2"}, root) == 1          # the list ends at the first invalid entry
+    assert bench.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "2"}, root) == 1
+    assert bench.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "3"}, root) == 0
+    assert bench.visible_gpu_count({"CUDA_VISIBLE_DEVICES": "0"}, root) == 1
+    assert bench.visible_gpu_count({"CUDA_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0,1,2"}, root) == 3
+    assert bench.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "GPU-abc2,GPU-abc4"}, root) == 2
+    assert bench.visible_gpu_count({"HIP_VISIBLE_DEVICES": ""}, root) == 0
+
+
+def test_ranks_get_disjoint_core_slices():
+    envs, log = [], []
+    bench.launch_ranks(4, [], device_count=4, popen=lambda cmd, env: (envs.append(env), _FakeProc(0, log))[1])
+    slices = [set(int(c) for c in e["MOLANN_BENCH_CPU_SLICE"].split(",")) for e in envs]
+    have = len(os.sched_getaffinity(0))
+    if have >= 4:
+        assert all(len(s) == have // 4 for s in slices)
+        assert len(set().union(*slices)) == sum(len(s) for s in slices)      # disjoint
+    assert bench.cpu_slice(2, 4, range(16)) == [8, 9, 10, 11] and bench.cpu_slice(0, 8, range(4)) == [0, 1, 2, 3]
+
+
+def test_traffic_is_quoted_only_for_the_kernel_it_was_measured_on():
+    a = "molann_lane_jit<NL=2> (plan-specialised; 14 consumer waves + 2 loader, ring of 15 tiles) grid=256 block=1024 lds=150000"
+    b = "molann_lane_jit<NL=2> (plan-specialised; 10 consumer waves + 2 loader, ring of 12 tiles) grid=256 block=768 lds=120000"
+    assert bench.kernel_names(a) == bench.kernel_names(b) == "molann_lane_jit<NL=2>"
+    assert bench.kernel_names("frames_ring_kernel<ND=8> (12 consumer) grid=256 || molann_mlp_chain<f32,FB=4> (plan-specialised) chunk=262144") \
+        == "frames_ring_kernel<ND=8> || molann_mlp_chain<f32,FB=4>"
+    assert bench.kernel_names("frames_lane_kernel<2,features_regs> grid=512") != bench.kernel_names(a)

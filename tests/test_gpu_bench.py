@@ -65,3 +65,28 @@ def test_debug_switch_refused_unless_diagnostic(hip_device):
     d = _line(_bench(["--steps", "2", "--warmup", "1", "--frames", "4096", "--no-cpu-baseline", "--diagnostic"],
                      {"MOLANN_ELIDE_INVARIANT_ALIGNMENT": "1"}))
     assert d["diagnostic"] is True and d["config"]["env"]["MOLANN_ELIDE_INVARIANT_ALIGNMENT"] == "1"
+
+
+def test_counting_devices_leaves_the_parent_without_a_gpu_context(hip_device):
+    """after the launcher has counted the GPUs, it holds no file descriptor on /dev/kfd (or a render
+    node) and torch has not initialised HIP - so forking + exec'ing the ranks from it is safe on this pool."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import bench, torch
+n = bench.visible_gpu_count()
+fds = []
+for fd in os.listdir("/proc/self/fd"):
+    try:
+        fds.append(os.readlink("/proc/self/fd/" + fd))
+    except OSError:
+        pass
+bad = [f for f in fds if "/dev/kfd" in f or "/dev/dri" in f]
+print("count", n, "initialized", torch.cuda.is_initialized(), "gpu_fds", bad)
+assert n >= 1 and not torch.cuda.is_initialized() and not bad
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, (p.stdout, p.stderr[-2000:])
+    import torch
+    assert ("count %d " % torch.cuda.device_count()) in p.stdout, p.stdout

@@ -197,3 +197,46 @@ def test_bf16_mlp_error_is_measured(hip_device):
 
 
 BF16_BOUND = 2.5e-3   # measured on MI355X (round 3): 1.18e-3 at output scale 0.35, and 4.5e-8 against the arithmetic model
+
+
+@pytest.mark.parametrize("n_inp", [86, 100, 301, 1000, 2503, 5000, 6570, 7000])
+def test_large_frame_alignment_through_the_ring(n_inp, hip_device, monkeypatch):
+    """AlignmentLayer.forward beyond the lane kernel's frame sizes: frames_align_ring_kernel (the dense frame staged once in an
+    LDS ring, groups of consumer waves per frame) for every frame that leaves room for two slots, frames_wave_kernel beyond.
+    Frame sizes that are / are not multiples of 16 bytes, alignment sets of 3 .. 400 atoms, batches around the grid's and the
+    ring's sizes; against the float64 oracle and against the gather kernel (MOLANN_NO_RING=1)."""
+    rng = np.random.default_rng(n_inp)
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    xyz -= xyz.mean(axis=0, keepdims=True)
+    u = Universe(xyz)
+    n_al = int(rng.choice([3, 40, min(400, n_inp // 2)]))
+    align = sorted(rng.choice(n_inp, size=n_al, replace=False).tolist())
+    al = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms).to(hip_device)
+    ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
+    g = torch.Generator().manual_seed(n_inp)
+    for n in (1, 37, 300, 1100 if n_inp <= 2503 else 530):
+        x = torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)
+        q = torch.randn((n, 4), generator=g)
+        q = q / q.norm(dim=1, keepdim=True)
+        x = (torch.einsum("nij,nkj->nki", wl.quaternion_to_matrix(q), x) + 2.0 * torch.randn((n, 1, 3), generator=g)).float().contiguous()
+        xd = x.to(hip_device)
+        with torch.no_grad():
+            got = al(xd)
+        info = last_launch_info(al)
+        assert ("frames_align_ring_kernel" in info) == (n_inp <= 6570), info
+        want = mo.align_forward(x.double(), align, ref_x)
+        own = float((mo.align_forward(x, align, ref_x.float()).double() - want).abs().max())     # the reference's arithmetic in fp32
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= max(1e-5, 2.0 * own), (n, err, own, info)
+        assert torch.equal(xd.cpu(), x)                                   # the input is never written
+        if n == 300:
+            # a view one frame in: 4-byte aligned input and output rows when the frame is not a multiple of 16 bytes
+            with torch.no_grad():
+                got1 = al(xd[1:])
+            assert torch.equal(got1, got[1:])
+            monkeypatch.setenv("MOLANN_NO_RING", "1")
+            with torch.no_grad():
+                old = al(xd)
+            assert "frames_wave_kernel" in last_launch_info(al)
+            monkeypatch.delenv("MOLANN_NO_RING")
+            assert float((old - got).abs().max()) <= max(2e-5, 4.0 * own)
