@@ -889,7 +889,7 @@ __global__ __launch_bounds__(1024) void frames_ring_kernel(const float* __restri
     }
 }
 
-#include "molann_align_ring.inc"
+#include "molann_align_regs.inc"
 
 // =============================================================================================
 // float64 path: the same forward for `model.double()(x.double())` (the reference follows x.dtype, ann.py:187-197)
@@ -1823,6 +1823,7 @@ struct molann_plan {
     char mlp_info[96];         // name + geometry of the last MLP kernel launch
     // large frames through frames_ring_kernel: per-frame window list, LDS positions of the alignment atoms and of the
     // items' atoms inside the staged image; ring_nd = LDS-DMA instructions per frame (0: frames_wave_kernel serves the plan)
+    int align_first;           // align_idx[0]
     int* d_ring_win;
     int* d_ring_align_pos;
     ItemDev* d_ring_items;
@@ -2511,32 +2512,35 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
 #undef LAUNCH_RING
         snprintf(p->last_info, sizeof(p->last_info), "frames_ring_kernel<ND=%d> (%d consumer + %d loader waves, ring of %d frames, %d windows) grid=%d block=%d lds=%zu",
                  nd, ra.n_cons, ra.n_load, ra.n_slot, p->ring_nwin, grid, block, lds);
-    } else if (mode == 1 && getenv("MOLANN_NO_RING") == nullptr && 12l * p->n_inp <= (163840 - ALIGN_RING_HEADER) / 2 - 1024) {
-        // AlignmentLayer.forward on large frames: the dense frame staged once in an LDS ring, groups of consumer waves
-        // per frame (frames_align_ring_kernel, molann_align_ring.inc)
-        AlignRingArgs ra;
+    } else if (mode == 1 && getenv("MOLANN_NO_RING") == nullptr && p->n_inp <= 24 * 512) {
+        // AlignmentLayer.forward on large frames: the frame held in the registers of a block of W waves (molann_align_regs.inc)
+        AlignRegsArgs ra;
         memset(&ra, 0, sizeof(ra));
         ra.n_frames = n_frames; ra.n_inp = p->n_inp; ra.n_align = p->n_align;
-        ra.frame_bytes = 12 * p->n_inp;
-        ra.n_chunks = ra.frame_bytes / 16;
-        ra.tail_dw = (ra.frame_bytes % 16) / 4;
-        const int dma_kib = ra.n_chunks / 64 + ((ra.n_chunks % 64) ? 1 : 0);
-        ra.slot_bytes = ceil_to(std::max(dma_kib * 1024, ra.n_chunks * 16 + 16), 1024);
-        ra.n_slot = std::min(16, (163840 - ALIGN_RING_HEADER) / ra.slot_bytes);
-        ra.n_load = ra.frame_bytes >= 16384 ? 2 : 4;
-        ra.n_group = std::max(1, std::min(12, ra.n_slot - ra.n_load));
-        ra.group_waves = std::max(1, 8 / ra.n_group);
-        ra.n_cons = ra.n_group * ra.group_waves;
-        ra.out_wide = (a.out_wide && (ra.frame_bytes % 16) == 0) ? 1 : 0;
-        { const char* e = getenv("MOLANN_RING_NT"); ra.nt = e ? (e[0] == '1') : 1; }
-        const int block = 64 * (ra.n_cons + ra.n_load);
-        const size_t lds = (size_t)ALIGN_RING_HEADER + (size_t)ra.n_slot * ra.slot_bytes;
-        const int grid = (int)std::min<long>(n_frames, p->num_cus);
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)frames_align_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr_done = true; }
-        hipLaunchKernelGGL(frames_align_ring_kernel, dim3(grid), dim3(block), lds, stream, x, out, p->d_align_idx, p->d_ref, p->d_ref64, ra);
-        snprintf(p->last_info, sizeof(p->last_info), "frames_align_ring_kernel (%d groups x %d consumer waves + %d loader waves, ring of %d frames of %d bytes) grid=%d block=%d lds=%zu",
-                 ra.n_group, ra.group_waves, ra.n_load, ra.n_slot, ra.slot_bytes, grid, block, lds);
+        ra.first_align = p->align_first;
+        { const char* e = diag_env("MOLANN_DEBUG_ALIGN_FLAGS"); ra.flags = e ? atoi(e) : 0; }
+        int W = 1;
+        while ((p->n_inp + 64 * W - 1) / (64 * W) > 24) W *= 2;
+        const int units = ((p->n_inp + 64 * W - 1) / (64 * W) + 3) / 4;       // atoms per thread, in fours
+        const void* fn = nullptr;
+#define ALIGN_REGS_CASE(WW, U) if (W == WW && units == U) fn = (const void*)frames_align_regs_kernel<WW, U>;
+        ALIGN_REGS_CASE(1, 1) ALIGN_REGS_CASE(1, 2) ALIGN_REGS_CASE(1, 3) ALIGN_REGS_CASE(1, 4) ALIGN_REGS_CASE(1, 5) ALIGN_REGS_CASE(1, 6)
+        ALIGN_REGS_CASE(2, 4) ALIGN_REGS_CASE(2, 5) ALIGN_REGS_CASE(2, 6) ALIGN_REGS_CASE(4, 4) ALIGN_REGS_CASE(4, 5) ALIGN_REGS_CASE(4, 6)
+        ALIGN_REGS_CASE(8, 4) ALIGN_REGS_CASE(8, 5) ALIGN_REGS_CASE(8, 6)
+#undef ALIGN_REGS_CASE
+        if (!fn) return MOLANN_E_UNSUPPORTED;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64 * (W + 1), 0) != hipSuccess || occ < 1) occ = 1;
+        // frames in flight per CU: two blocks of the 5000-atom class (measured, A4: 7.9 / 6.4 / 7.4 ms per 262 144 frames at 1 / 2 / 3
+        // blocks per CU), more of the smaller ones: about 120 KB of frames per CU
+        occ = std::min(occ, std::max(2, (int)(122880 / (12l * p->n_inp))));
+        if (debug_env().wave_bpc > 0) occ = std::min(occ, debug_env().wave_bpc);
+        const int grid = (int)std::min<long>(n_frames, (long)p->num_cus * occ);
+        void* kargs[] = {(void*)&x, (void*)&out, (void*)&p->d_align_idx, (void*)&p->d_ref, (void*)&p->d_ref64, (void*)&ra};
+        const hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * (W + 1)), kargs, 0, stream);
+        snprintf(p->last_info, sizeof(p->last_info), "frames_align_regs_kernel<W=%d,U=%d> (%d data waves + 1 solver per frame, %d atoms per thread, %d blocks per CU) grid=%d block=%d",
+                 W, units, W, 4 * units, occ, grid, 64 * (W + 1));
+        if (le != hipSuccess) return (int)le;
     } else {
         const int wpb = 4;
         // blocks per CU: all wave slots.  (The gather is HBM-latency bound and wants every wave it can get; the MLP
@@ -2691,6 +2695,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     p->n_inp = d->n_inp;
     p->n_align = d->n_align;
+    p->align_first = d->n_align > 0 ? d->align_idx[0] : 0;
     p->n_features = d->n_features;
     p->n_items = (int)items.size();
     p->d_feat = d_feat;

@@ -384,8 +384,8 @@ def round3_main():
     w = wl.get_workload("A4")
     uc = Universe(w.ref_xyz)
     allc = list(range(1, w.n_atoms + 1))
-    run_case("align_chain5000", uc, w.make_frames(8, seed=w.seed), allc, align=list(w.align), kind="align",
-             x_recipe={"workload": "A4", "frames": 8, "seed": w.seed})
+    # (x is stored: the rigid motion of A4's frames is a batched matmul whose rounding differs between hosts)
+    run_case("align_chain5000", uc, w.make_frames(6, seed=w.seed), allc, align=list(w.align), kind="align")
     xyz301 = w.ref_xyz[:301] - w.ref_xyz[:301].mean(axis=0, keepdims=True)
     u301 = Universe(xyz301)
     run_case("align_chain301", u301, noisy(xyz301, 70, 0.1, 301, rigid=True), list(range(1, 302)), align=list(range(3, 302, 7)),

@@ -199,12 +199,12 @@ def test_bf16_mlp_error_is_measured(hip_device):
 BF16_BOUND = 2.5e-3   # measured on MI355X (round 3): 1.18e-3 at output scale 0.35, and 4.5e-8 against the arithmetic model
 
 
-@pytest.mark.parametrize("n_inp", [86, 100, 301, 1000, 2503, 5000, 6570, 7000])
-def test_large_frame_alignment_through_the_ring(n_inp, hip_device, monkeypatch):
-    """AlignmentLayer.forward beyond the lane kernel's frame sizes: frames_align_ring_kernel (the dense frame staged once in an
-    LDS ring, groups of consumer waves per frame) for every frame that leaves room for two slots, frames_wave_kernel beyond.
-    Frame sizes that are / are not multiples of 16 bytes, alignment sets of 3 .. 400 atoms, batches around the grid's and the
-    ring's sizes; against the float64 oracle and against the gather kernel (MOLANN_NO_RING=1)."""
+@pytest.mark.parametrize("n_inp", [86, 100, 301, 1000, 1537, 2503, 5000, 6570, 12288, 12400])
+def test_large_frame_alignment_in_registers(n_inp, hip_device, monkeypatch):
+    """AlignmentLayer.forward beyond the lane kernel's frame sizes: frames_align_regs_kernel (the frame held in the registers of a
+    block of 1, 2, 4 or 8 data waves + a solver wave) up to 12 288 atoms, frames_wave_kernel beyond.  Frame sizes that are /
+    are not multiples of 16 bytes, alignment sets of 3 .. 400 atoms, batches around the grid's size; against the float64
+    oracle and against the gather kernel (MOLANN_NO_RING=1)."""
     rng = np.random.default_rng(n_inp)
     xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
     xyz -= xyz.mean(axis=0, keepdims=True)
@@ -214,7 +214,7 @@ def test_large_frame_alignment_through_the_ring(n_inp, hip_device, monkeypatch):
     al = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms).to(hip_device)
     ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
     g = torch.Generator().manual_seed(n_inp)
-    for n in (1, 37, 300, 1100 if n_inp <= 2503 else 530):
+    for n in (1, 37, 300, 1100 if n_inp <= 2503 else (530 if n_inp <= 6570 else 260)):
         x = torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)
         q = torch.randn((n, 4), generator=g)
         q = q / q.norm(dim=1, keepdim=True)
@@ -223,7 +223,7 @@ def test_large_frame_alignment_through_the_ring(n_inp, hip_device, monkeypatch):
         with torch.no_grad():
             got = al(xd)
         info = last_launch_info(al)
-        assert ("frames_align_ring_kernel" in info) == (n_inp <= 6570), info
+        assert ("frames_align_regs_kernel" in info) == (n_inp <= 12288), info
         want = mo.align_forward(x.double(), align, ref_x)
         own = float((mo.align_forward(x, align, ref_x.float()).double() - want).abs().max())     # the reference's arithmetic in fp32
         err = float((got.cpu().double() - want).abs().max())
