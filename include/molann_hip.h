@@ -214,6 +214,15 @@ int molann_plan_backward_kind(molann_plan* plan);
 int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* grad_x,
                         float* grad_params, molann_stream_t stream);
 
+/* out[N, out_dim] = molann_forward_packed_f32(x) (molann_features_f32(x) for a plan without an MLP; MolANN.forward ann.py:620-624)
+ * AND grad_x[N, n_inp, 3] = the vector-Jacobian product for the cotangent grad_out[N, out_dim], in ONE launch: the one-pass
+ * backward recomputes the forward per frame anyway; this build of it also stores the outputs.  For a host that differentiates a
+ * small batch at every step (a collective variable and its forces inside an MD engine, README.rst:49): one launch instead of a
+ * forward and a backward.  The Jacobian of one frame: a batch of out_dim copies of it with the identity as grad_out.  Parameters
+ * are data (no parameter gradients).  Plans with molann_plan_backward_kind == 2, else MOLANN_E_UNSUPPORTED.  First call: hipRTC. */
+int molann_value_and_vjp_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* out,
+                             float* grad_x, molann_stream_t stream);
+
 /* molann_forward_packed_f32 that also writes features[N, feature_dim] (what molann_features_f32 would give), for a
  * backward through molann_mlp_backward_f32 + molann_features_backward_f32 without the recompute.  Plans whose MLP
  * is fused into the lane kernel (the ones molann_plan_supports_backward accepts with an MLP); same `out` bit for bit. */

@@ -98,6 +98,7 @@ def lib():
             "molann_plan_supports_backward": (i32, [vp]),
             "molann_plan_backward_kind": (i32, [vp]),
             "molann_backward_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
+            "molann_value_and_vjp_f32": (i32, [vp, vp, vp, i64, vp, vp, vp]),
             "molann_forward_train_f32": (i32, [vp, vp, i64, vp, vp, vp]),
             "molann_features_backward_f64": (i32, [vp, vp, vp, i64, vp, vp]),
             "molann_features_backward_f32": (i32, [vp, vp, vp, i64, vp, vp]),
@@ -287,6 +288,14 @@ class Plan(object):
                                         torch.cuda.current_stream().cuda_stream)
         if code != 0:
             raise MolannHipError(code, "molann_backward_f32")
+
+    def value_and_vjp(self, x, grad_out, out, grad_x):
+        """out = forward(x) and grad_x = the vector-Jacobian product for `grad_out`, one launch (plans with backward_kind() == 2)."""
+        code = _lib.molann_value_and_vjp_f32(self._handle, x.data_ptr(), grad_out.data_ptr(), x.shape[0], out.data_ptr(), grad_x.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+        if code != 0:
+            raise MolannHipError(code, "molann_value_and_vjp_f32")
+        return out, grad_x
 
     def forward_train(self, x, out, features):
         """`forward_packed` that also keeps the features (for `mlp_backward` + `features_backward`)."""

@@ -628,6 +628,37 @@ class MolANN(_PlanOwner, torch.nn.Module):
             entry.sync_mlp(st["linears"])
         return entry.plan
 
+    def value_and_vjp(self, x, grad_out, into=None):
+        """``(y, dx)`` with ``y = self(x)`` and ``dx = sum_k grad_out[:, k] d y[:, k] / d x`` in ONE kernel launch
+        (`molann_value_and_vjp_f32`: the one-pass backward recomputes the forward anyway and, in this build, stores it too).
+        For a caller that needs a collective variable and its forces at every step (`README.rst:49`): ~half the host time of a
+        forward plus a backward.  The Jacobian of one frame: ``x.expand(d_out, -1, -1)`` with ``torch.eye(d_out)`` as cotangent.
+        No autograd graph is recorded (parameters are data); ``into=(y, dx)`` reuses the caller's buffers.  Models served by one
+        fused plan whose backward is the one-pass kernel, float32."""
+        st = self._fast_state(x) if isinstance(x, torch.Tensor) and x.is_cuda else None
+        if st is None or not st["fused"]:
+            raise NotImplementedError("value_and_vjp needs a model served by one fused plan on a HIP device")
+        al, fl = st["al"], st["fl"]
+        _check_input(x, fl.input_atom_num)
+        if x.dtype != torch.float32:
+            raise TypeError("value_and_vjp is float32 only; got %s" % x.dtype)
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        lins = st["linears"]
+        if st["op"] is not None:
+            y, dx = st["op_vjp"](x, st["desc"], _device_buffer(al.ref_x, x) if al is not None else st["no_ref"],
+                                 [lin.weight for lin in lins], [lin.bias for lin in lins], grad_out, list(into) if into is not None else [])
+            return y, dx
+        entry = st["entry"]()
+        with torch.cuda.device(x.device):
+            if al is not None:
+                entry.sync_ref(_device_buffer(al.ref_x, x))
+            entry.sync_mlp(lins)
+            y, dx = into if into is not None else (torch.empty((x.shape[0], st["out_dim"]), dtype=torch.float32, device=x.device), torch.empty_like(x))
+            g = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.float().contiguous()
+            entry.plan.value_and_vjp(x, g, y, dx)
+        return y, dx
+
     def last_launch_info(self):
         """Name + geometry of the kernels the last forward launched (bench / profiles / tests)."""
         st = self.__dict__.get("_fast")
@@ -672,6 +703,7 @@ class MolANN(_PlanOwner, torch.nn.Module):
             # ctypes for a 1024-frame batch (tools/latency_c1.py)
             st["op"] = _run_op()
             if st["op"] is not None:
+                st["op_vjp"] = torch.ops.molann.value_and_vjp
                 from . import script
                 st["desc"] = script.make_desc(script.KIND_FORWARD, fl.input_atom_num,
                                               align_idx=al._local_align_atom_indices if al is not None else None,

@@ -1791,6 +1791,9 @@ struct molann_plan {
     hipModule_t rbwd_mod;
     hipFunction_t rbwd_fn;     // the whole backward in one pass over x (molann_bwd_ring.inc), compiled at the first backward
     int rbwd_state, rbwd_ncons, rbwd_nload, rbwd_nslot, rbwd_lds;
+    hipModule_t vjp_mod;
+    hipFunction_t vjp_fn;      // the one-pass backward that also stores the forward's outputs (molann_value_and_vjp_f32), same geometry
+    int vjp_state;
     hipModule_t mbwd_mod;
     hipFunction_t mbwd_fn;     // backward of the fused family's MLP (molann_mlp_bwd.inc), compiled at the first backward
     int mbwd_state, mbwd_wpb;
@@ -1984,6 +1987,7 @@ struct JitSpec { // what the specialised kernel is compiled for
     int waves_per_eu = 2;             // occupancy the backward kernel is compiled for (amdgpu_waves_per_eu)
     int nbuf = 1;
     bool save_feat = false;           // forward kernel: also writes the features (training; molann_forward_train_f32)
+    bool with_values = false;         // one-pass backward kernel: also writes the forward's outputs (molann_value_and_vjp_f32)
     bool frag_lds = false;            // one-pass backward: weight fragments in an LDS image at img_off instead of registers
     int img_off = 0;
     // forward kernel: loader / consumer block around a ring of tile slots (molann_lane_jit.inc)
@@ -2138,6 +2142,7 @@ std::string jit_source_mlp_bwd(const JitSpecBox& b, int wpb) {
     arr("DIMS", dims); arr("KP", kp); arr("JP", jp); arr("WOFF", woff); arr("GOFF", goff);
     K("N_PARAMS", (int)g);
     s += "constexpr bool FRAG_LDS = false;\n";   // this kernel's waves have the registers for their weight fragments
+    s += "constexpr bool WITH_VALUES = false;\n";
     s += "#line 1 \"molann_mlp_tile.inc\"\n";
     s += join_chunks(k_src_molann_mlp_tile_inc);
     s += "#line 1 \"molann_mlp_bwd.inc\"\n";
@@ -2233,6 +2238,7 @@ std::string jit_preamble(const JitSpec& j) {
     K("NCONS", j.ncons); K("NLOAD", j.nload); K("LDS_BLOCK", j.lds_block); K("NSLOT", j.nslot); K("DEPTH", j.depth); K("RING_OFF", j.ring_off); K("TILE_STRIDE", j.tile_stride);
     K("FB_OFF", j.fb_off); K("FB_BYTES", j.fb_bytes);
     s += j.save_feat ? "constexpr bool SAVE_FEAT = true;\n" : "constexpr bool SAVE_FEAT = false;\n";
+    s += j.with_values ? "constexpr bool WITH_VALUES = true;\n" : "constexpr bool WITH_VALUES = false;\n";
     s += j.frag_lds ? "constexpr bool FRAG_LDS = true;\n" : "constexpr bool FRAG_LDS = false;\n";
     K("IMG_OFF", j.img_off);
     {   // waves per SIMD the forward kernel must fit (its register budget): every wave of the (NCONS + 1)-wave blocks
@@ -3119,6 +3125,7 @@ int molann_plan_destroy(molann_plan* p) {
     if (p->bwd_mod) (void)hipModuleUnload(p->bwd_mod);
     if (p->mbwd_mod) (void)hipModuleUnload(p->mbwd_mod);
     if (p->rbwd_mod) (void)hipModuleUnload(p->rbwd_mod);
+    if (p->vjp_mod) (void)hipModuleUnload(p->vjp_mod);
     if (p->feat_mod) (void)hipModuleUnload(p->feat_mod);
     if (p->train_mod) (void)hipModuleUnload(p->train_mod);
     if (p->align_mod) (void)hipModuleUnload(p->align_mod);
@@ -3550,24 +3557,25 @@ int ensure_ring_bwd(molann_plan* p) {
 }
 
 // molann_bwd_ring (+ reduce_rows_kernel); with parameter gradients the caller holds the workspace (BwdGuard)
-int launch_ring_bwd(molann_plan* p, const float* x, const float* grad_out, long n, float* grad_x, float* grad_params, hipStream_t stream) {
+int launch_ring_bwd(molann_plan* p, const float* x, const float* grad_out, long n, float* grad_x, float* grad_params, hipStream_t stream,
+                    float* values = nullptr) {
     const long n_tiles = (n + 63) / 64;
     const int grid = (int)std::max<long>(1, std::min<long>(p->num_cus, n_tiles));
     const bool params = grad_params && p->n_grad_params > 0;
-    struct { const float* x; const float* gout; const double* ref64; const float* ref32; const float* wnat; float* gx; float* gp; long n; } ka =
-        {x, grad_out, p->d_ref64, p->d_ref, (const float*)p->d_wmfma, grad_x, params ? p->d_gpart : nullptr, n};
+    struct { const float* x; const float* gout; const double* ref64; const float* ref32; const float* wnat; float* gx; float* gp; long n; float* y; } ka =
+        {x, grad_out, p->d_ref64, p->d_ref, (const float*)p->d_wmfma, grad_x, params ? p->d_gpart : nullptr, n, values};
     size_t ksz = sizeof(ka);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
     const int block = 64 * (p->rbwd_ncons + p->rbwd_nload);
-    const hipError_t le = hipModuleLaunchKernel(p->rbwd_fn, grid, 1, 1, block, 1, 1, 0, stream, nullptr, cfg);
+    const hipError_t le = hipModuleLaunchKernel(values ? p->vjp_fn : p->rbwd_fn, grid, 1, 1, block, 1, 1, 0, stream, nullptr, cfg);
     if (le != hipSuccess) return (int)le;
     if (params) {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((p->n_grad_params + 63) / 64), dim3(1024), 0, stream, p->d_gpart, grid, p->n_grad_params,
                            grad_params);
         HIP_TRY(hipGetLastError());
     }
-    snprintf(p->last_info, sizeof(p->last_info), "molann_bwd_ring (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d%s",
-             p->rbwd_ncons, p->rbwd_nload, p->rbwd_nslot, grid, block, p->rbwd_lds, params ? " + reduce_rows_kernel" : "");
+    snprintf(p->last_info, sizeof(p->last_info), "molann_bwd_ring%s (plan-specialised; %d consumer waves + %d loader, ring of %d tiles) grid=%d block=%d lds=%d%s",
+             values ? "<values>" : "", p->rbwd_ncons, p->rbwd_nload, p->rbwd_nslot, grid, block, p->rbwd_lds, params ? " + reduce_rows_kernel" : "");
     return MOLANN_OK;
 }
 
@@ -3696,6 +3704,53 @@ int molann_backward_f32(molann_plan* p, const float* x, const float* grad_out, i
     }
     if (rc == MOLANN_OK) snprintf(p->last_info, sizeof(p->last_info), "%.80s || %.80s || %.80s", info[0], info[1], info[2]);
     return rc;
+}
+
+// The forward's outputs AND the vector-Jacobian product of a batch in ONE launch: the one-pass backward recomputes the forward per
+// frame anyway, so a build of it that also stores the outputs (WITH_VALUES: one more product on the matrix cores, from the
+// activations already in its scratch) returns both.  For callers that differentiate a small batch at every step with a cotangent
+// they know up front - or want the Jacobian: a batch of d_out copies of a frame with the identity as cotangent (README.rst:49's
+// use, a collective variable inside an MD engine).  Parameters are data here (no parameter gradients).  Plans the one-pass
+// backward serves (molann_plan_backward_kind == 2); E_UNSUPPORTED otherwise.  The first call builds the kernel: outside a capture.
+int molann_value_and_vjp_f32(molann_plan* p, const float* x, const float* grad_out, int64_t n, float* out, float* grad_x, molann_stream_t stream) {
+    if (!p) return MOLANN_E_NULL;
+    if (n < 0) return MOLANN_E_DESC;
+    if (n == 0) return MOLANN_OK;
+    if (!x || !grad_out || !out || !grad_x) return MOLANN_E_NULL;
+    if ((((uintptr_t)x) & 3) || (((uintptr_t)grad_out) & 3) || (((uintptr_t)grad_x) & 3) || (((uintptr_t)out) & 3)) return MOLANN_E_ALIGNMENT;
+    if (!p->spec || p->n_items <= 0 || !p->geom[0].ok) return MOLANN_E_UNSUPPORTED;
+    if (p->n_layers > 0 && (!molann_plan_supports_backward(p) || !p->fused_mlp)) return MOLANN_E_UNSUPPORTED;
+    if (p->n_layers > 0 && !p->mlp_packed) return MOLANN_E_NOT_PACKED;
+    const int er = ensure_ring_bwd(p);       // the geometry is the one-pass backward's
+    if (er != MOLANN_OK) return er;
+    if (p->vjp_state == 0) {
+        std::lock_guard<std::mutex> lock(*p->jit_mu);
+        if (p->vjp_state == 0) {
+            int st = -1;
+            JitSpecBox b = *p->spec;
+            if (bwd_ring_geometry(b.j, p->n_grad_params)) {
+                b.j.with_values = true;
+                const std::string src = jit_source_bwd_ring(b);
+                for (int attempt = 0; attempt < 2 && st != 1; ++attempt) {   // (scratch is tolerated here: a latency path, not a throughput path)
+                    std::vector<char> code;
+                    std::string log;
+                    hipModule_t mod = nullptr;
+                    hipFunction_t fn = nullptr;
+                    if (jit_compile(src, code, log, attempt == 0 ? "-fno-slp-vectorize" : nullptr) == 0 && hipModuleLoadData(&mod, code.data()) == hipSuccess &&
+                        hipModuleGetFunction(&fn, mod, "molann_bwd_ring") == hipSuccess) {
+                        p->vjp_mod = mod; p->vjp_fn = fn;
+                        st = 1;
+                    } else {
+                        if (mod) (void)hipModuleUnload(mod);
+                        if (getenv("MOLANN_JIT_VERBOSE")) fprintf(stderr, "molann value + vjp build %d failed\n%s\n", attempt, log.c_str());
+                    }
+                }
+            }
+            p->vjp_state = st;
+        }
+    }
+    if (p->vjp_state != 1) return MOLANN_E_UNSUPPORTED;
+    return launch_ring_bwd(p, x, grad_out, (long)n, grad_x, nullptr, (hipStream_t)stream, out);
 }
 
 // how molann_backward_f32 will serve this plan: 2 one pass over x (nothing worth saving from the forward), 1 two kernels
@@ -3827,6 +3882,7 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
             long np = 0;
             for (int l = 0; l < j.n_layers; ++l) np += (long)j.dims[l + 1] * j.dims[l] + j.dims[l + 1];
             if (!bwd_ring_geometry(b.j, (int)np)) return MOLANN_E_UNSUPPORTED;
+            b.j.with_values = (do_compile & 64) != 0;          // ... the build that also stores the forward's outputs (molann_value_and_vjp_f32)
             src = jit_source_bwd_ring(b);
         } else if (do_compile & 8) { // ... its MLP half (molann_mlp_bwd.inc)
             if (j.n_layers <= 0) return MOLANN_E_STAGE;

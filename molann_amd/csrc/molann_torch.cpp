@@ -346,6 +346,40 @@ std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int
     return {gx, gp};
 }
 
+// {out, grad_x}: the forward's outputs and the vector-Jacobian product for grad_out in ONE launch (molann_value_and_vjp_f32: the
+// one-pass backward that also stores the outputs).  Parameters are data.  `into` (optional: {out, grad_x} of the right shapes)
+// is written instead of fresh tensors - a caller at every MD step keeps its two buffers.
+std::vector<at::Tensor> value_and_vjp_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                                          std::vector<at::Tensor> biases, const at::Tensor& grad_out, std::vector<at::Tensor> into) {
+    check_x(x_in, desc);
+    TORCH_CHECK(x_in.scalar_type() == at::kFloat, "molann::value_and_vjp: float32 only");
+    const at::Tensor x = x_in.contiguous();
+    const c10::DeviceGuard guard(x.device());
+    const bool align_only = desc[1] == KIND_ALIGN;
+    auto e = entry_for(align_only ? align_as_features(desc) : desc, x, ref_x);
+    const int64_t n = x.size(0);
+    const int64_t cols = e->kind == KIND_FORWARD ? e->out_dim : e->feature_dim;
+    at::Tensor g = grad_out.scalar_type() == at::kFloat && grad_out.is_contiguous() ? grad_out : grad_out.to(at::kFloat).contiguous();
+    TORCH_CHECK(g.numel() == n * cols && g.device() == x.device(), "molann::value_and_vjp: grad_out must be [", n, ", ", cols, "] on ", x.device());
+    at::Tensor out, gx;
+    if (into.size() == 2) {
+        out = into[0]; gx = into[1];
+        TORCH_CHECK(out.is_contiguous() && gx.is_contiguous() && out.scalar_type() == at::kFloat && gx.scalar_type() == at::kFloat &&
+                    out.numel() == n * cols && gx.numel() == x.numel() && out.device() == x.device() && gx.device() == x.device(),
+                    "molann::value_and_vjp: `into` must be contiguous float32 {[N, out_dim], [N, n_inp, 3]} on x's device");
+    } else {
+        out = at::empty({n, cols}, x.options());
+        gx = at::empty_like(x);
+    }
+    if (n == 0) return {out, gx};
+    hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    sync_live(*e, x, ref_x, weights, biases, stream);
+    check(molann_value_and_vjp_f32(e->plan, x.data_ptr<float>(), g.data_ptr<float>(), n, out.data_ptr<float>(), gx.data_ptr<float>(), stream),
+          "molann_value_and_vjp_f32");
+    return {out, gx};
+}
+
 // The fused forward that also keeps the features: {out, features} - or {out, empty} where the plan has no such twin of its
 // kernel (molann_plan_backward_kind != 1 ... != 2 plans recompute in molann_backward_f32).  float32 fused plans.
 std::vector<at::Tensor> run_train_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
@@ -665,6 +699,7 @@ TORCH_LIBRARY(molann, m) {
           "bool need_params) -> Tensor[]");
     m.def("run_train(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor[]");
     m.def("run_backward_mlp(Tensor feat, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out) -> Tensor");
+    m.def("value_and_vjp(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, Tensor[] into) -> Tensor[]");
     m.def("supports_backward(Tensor x, int[] desc, Tensor ref_x) -> int", supports_backward);
     m.def("launch_info(int[] desc, int device) -> str", launch_info);
     m.def("invalidate(int[] desc, int device) -> ()", invalidate);
@@ -680,6 +715,7 @@ TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP devic
     m.impl("run_backward", run_backward_hip);
     m.impl("run_train", run_train_hip);
     m.impl("run_backward_mlp", run_backward_mlp_hip);
+    m.impl("value_and_vjp", value_and_vjp_hip);
 }
 
 TORCH_LIBRARY_IMPL(molann, Autograd, m) { m.impl("run", run_autograd); }

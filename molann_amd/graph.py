@@ -94,6 +94,9 @@ class GraphedForces(GraphedForward):
         self._plan = plan
         self.static_dy = torch.zeros_like(self.static_y)
         self.static_dx = torch.empty_like(x)
+        self.static_y2 = torch.empty_like(self.static_y)
+        with torch.cuda.device(x.device):
+            self.model.value_and_vjp(x, self.static_dy, into=(self.static_y2, self.static_dx))    # builds that kernel now
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side), torch.cuda.device(x.device):
@@ -105,6 +108,16 @@ class GraphedForces(GraphedForward):
         with torch.cuda.graph(self.bwd_graph), torch.cuda.device(x.device):
             plan.backward(x, self.static_dy, self.static_dx, None)
         return self
+
+    def value_and_vjp(self, x, dy):
+        """``(y, dx)`` of one launch of `molann_value_and_vjp_f32` on fresh `x` and `dy` (no graph: a direct launch from an idle
+        stream costs less host time than a graph replay plus the two copies into its static buffers) into this object's
+        static buffers - clone to keep.  For callers that know the cotangent before the values (a linear bias, or the Jacobian:
+        the identity as cotangent on a batch of copies)."""
+        if x.shape != self.static_x.shape or dy.shape != self.static_dy.shape:
+            raise ValueError("GraphedForces was captured for %s / %s, got %s / %s" % (tuple(self.static_x.shape), tuple(self.static_dy.shape),
+                                                                                    tuple(x.shape), tuple(dy.shape)))
+        return self.model.value_and_vjp(x, dy, into=(self.static_y2, self.static_dx))
 
     def vjp(self, dy):
         if dy.shape != self.static_dy.shape:

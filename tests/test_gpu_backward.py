@@ -445,3 +445,91 @@ def test_a_nan_frame_poisons_only_itself(hip_device):
     assert torch.isfinite(xb.grad[keep]).all()
     assert torch.equal(xb.grad[keep], xa.grad[keep])
     assert torch.isnan(xb.grad[bad][:, [a - 1 for a in w.touched_atoms()]]).all()
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C3", "C3p"])
+@pytest.mark.parametrize("n", [1, 8, 64, 65, 1000])
+def test_value_and_vjp_in_one_launch(cfg, n, hip_device):
+    """molann_value_and_vjp_f32 (the one-pass backward that also stores the forward's outputs): values against the forward
+    kernel, the vector-Jacobian product against eager autograd, through the module method, the ctypes plan and `into=`."""
+    from build_util import workload_model
+    from molann_amd import workloads as wl
+    from molann_amd.ann import MolANN
+    w = wl.get_workload(cfg)
+    model = workload_model(w, hip_device).requires_grad_(False)
+    x = w.make_frames(n, seed=50 + n).to(hip_device)
+    dy = torch.randn((n, w.out_dim()), generator=torch.Generator().manual_seed(n)).to(hip_device)
+    xe = x.clone().requires_grad_(True)
+    ye = model(xe)
+    (dxe,) = torch.autograd.grad(ye, xe, dy)
+    if isinstance(model, MolANN):
+        y, dx = model.value_and_vjp(x, dy)
+        assert "molann_bwd_ring<values>" in model.last_launch_info(), model.last_launch_info()
+        plan = model.plan_for(x)
+    else:       # a PreprocessingANN: through its plan
+        plan = model._plans()[("features", hip_device.index)].plan
+        y, dx = torch.empty_like(ye), torch.empty_like(x)
+        with torch.cuda.device(hip_device):
+            plan.value_and_vjp(x, dy, y, dx)
+    scale = max(1.0, float(dxe.abs().max()))
+    assert float((y - ye.detach()).abs().max()) <= 2e-6 * max(1.0, float(ye.abs().max()))
+    assert float((dx - dxe).abs().max()) <= 1e-6 * scale
+    y2, dx2 = torch.full_like(y, float("nan")), torch.full_like(dx, float("nan"))
+    with torch.cuda.device(hip_device):
+        plan.value_and_vjp(x, dy, y2, dx2)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y) and torch.equal(dx2, dx)
+    if isinstance(model, MolANN):
+        y3, dx3 = torch.empty_like(y), torch.empty_like(dx)
+        r = model.value_and_vjp(x, dy, into=(y3, dx3))
+        assert r[0].data_ptr() == y3.data_ptr() and torch.equal(y3, y) and torch.equal(dx3, dx)
+
+
+def test_value_and_vjp_latency_and_jacobian(hip_device):
+    """The MD-step use: values + forces of 1 .. 64 frames per call (host time per call printed), and the Jacobian of one frame's
+    values from one launch on d_out copies of it."""
+    import time
+    from build_util import workload_model
+    from molann_amd import workloads as wl
+    from molann_amd.graph import GraphedForces
+    w = wl.get_workload("C3")
+    model = workload_model(w, hip_device).requires_grad_(False)
+    for n in (1, 64):
+        x = w.make_frames(n, seed=3).to(hip_device)
+        dy = torch.randn((n, w.out_dim()), generator=torch.Generator().manual_seed(5)).to(hip_device)
+        y, dx = torch.empty((n, w.out_dim()), device=hip_device), torch.empty_like(x)
+        for _ in range(20):
+            model.value_and_vjp(x, dy, into=(y, dx))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(500):
+            model.value_and_vjp(x, dy, into=(y, dx))
+        torch.cuda.synchronize()
+        t_into = (time.perf_counter() - t0) / 500 * 1e6
+        t0 = time.perf_counter()
+        for _ in range(500):
+            model.value_and_vjp(x, dy)
+        torch.cuda.synchronize()
+        t_fresh = (time.perf_counter() - t0) / 500 * 1e6
+        g = GraphedForces(model, x)
+        for _ in range(20):
+            g(x); g.vjp(dy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(500):
+            g(x); g.vjp(dy)
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / 500 * 1e6
+        print("values + forces, %d frame(s): %.1f us per call (one launch, caller's buffers), %.1f (fresh tensors), %.1f (two graph replays)"
+              % (n, t_into, t_fresh, t_graph))
+        yg, dxg = g.value_and_vjp(x, dy)
+        assert torch.equal(yg, y) and torch.equal(dxg, dx)
+    d_out = w.out_dim()
+    x1 = w.make_frames(1, seed=9).to(hip_device)
+    yj, J = model.value_and_vjp(x1.expand(d_out, -1, -1).contiguous(), torch.eye(d_out, device=hip_device))
+    xe = x1.clone().requires_grad_(True)
+    ye = model(xe)
+    assert float((yj[0] - ye.detach()[0]).abs().max()) <= 2e-6
+    for k in range(d_out):
+        (gk,) = torch.autograd.grad(ye[0, k], xe, retain_graph=True)
+        assert float((J[k] - gk[0]).abs().max()) <= 1e-6 * max(1.0, float(gk.abs().max()))

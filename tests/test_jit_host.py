@@ -23,7 +23,7 @@ def test_specialised_kernel_compiles(name):
     assert "molann_lane_jit" in src
 
 
-@pytest.mark.parametrize("mode,entry", [(3, "molann_lane_bwd"), (11, "molann_mlp_bwd"), (19, "molann_bwd_ring")])
+@pytest.mark.parametrize("mode,entry", [(3, "molann_lane_bwd"), (11, "molann_mlp_bwd"), (19, "molann_bwd_ring"), (83, "molann_bwd_ring")])
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C3p"])
 def test_backward_kernels_compile(name, mode, entry):
     """The plan-specialised backward kernels (preprocessing half, MLP half, one pass) cross-compile for gfx950."""
