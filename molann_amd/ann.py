@@ -284,6 +284,7 @@ class _PlanOwner(object):
         state = dict(self.__dict__)
         state.pop("_plan_cache", None)
         state.pop("_fast", None)
+        state.pop("_fp", None)
         return state
 
     def __deepcopy__(self, memo):
@@ -292,7 +293,7 @@ class _PlanOwner(object):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ("_plan_cache", "_fast"):
+            if k not in ("_plan_cache", "_fast", "_fp"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
@@ -646,7 +647,7 @@ class MolANN(_PlanOwner, torch.nn.Module):
         x = x if x.is_contiguous() else x.contiguous()
         lins = st["linears"]
         if st["op"] is not None:
-            y, dx = st["op_vjp"](x, st["desc"], _device_buffer(al.ref_x, x) if al is not None else st["no_ref"],
+            y, dx = st["op_vjp"](x, st["handle"], _device_buffer(al.ref_x, x) if al is not None else st["no_ref"],
                                  [lin.weight for lin in lins], [lin.bias for lin in lins], grad_out, list(into) if into is not None else [])
             return y, dx
         entry = st["entry"]()
@@ -703,19 +704,41 @@ class MolANN(_PlanOwner, torch.nn.Module):
             # ctypes for a 1024-frame batch (tools/latency_c1.py)
             st["op"] = _run_op()
             if st["op"] is not None:
-                st["op_vjp"] = torch.ops.molann.value_and_vjp
+                st["op_vjp"] = torch.ops.molann.value_and_vjp_h
                 from . import script
                 st["desc"] = script.make_desc(script.KIND_FORWARD, fl.input_atom_num,
                                               align_idx=al._local_align_atom_indices if al is not None else None,
                                               features=spec, use_angle_value=uav, layer_dims=dims, activation=act,
                                               mlp_precision=_capi.MLP_BF16 if self.mlp_precision == "bf16" else _capi.MLP_F32)
                 st["no_ref"] = torch.zeros(0, 3)
+                st["handle"] = torch.ops.molann.register_desc(st["desc"])
                 import weakref
                 weakref.finalize(self, _release_plans, st["desc"], x.device.index)
+                # the inference fast path of forward(): everything it compares or passes, looked up once
+                self.__dict__["_fp"] = (x.device, (fl.input_atom_num, 3), pp, nn, al, fl, len(nn._modules), st["handle"], torch.ops.molann.run_h,
+                                        st["no_ref"], [lin._parameters for lin in linears], self.mlp_precision)
+        if not (st["fused"] and st.get("op") is not None):
+            self.__dict__.pop("_fp", None)
         self.__dict__["_fast"] = st
         return st
 
     def forward(self, x):
+        # ---- inference fast path (a 1024-frame call is ~3 us of kernel: the host side is what a caller waits for; tools/latency_breakdown.py).
+        # Taken only when nothing it skips could matter: the same module objects as when the plan was made, a float32 [N > 0, n_inp, 3]
+        # tensor on the plan's device, nothing to record for autograd.  Everything else takes the general path below, checks and all.
+        fp = self.__dict__.get("_fp")
+        if fp is not None and type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == fp[0] and x.dim() == 3 \
+                and tuple(x.shape[1:]) == fp[1] and x.shape[0] > 0:
+            mods = self._modules
+            pp, nn = fp[2], fp[3]
+            if mods["preprocessing_layer"] is pp and mods["ann_layers"] is nn and len(nn._modules) == fp[6] and self.mlp_precision == fp[11] \
+                    and pp._modules["feature_layer"] is fp[5] and (pp._modules["align_layer"] is fp[4] or fp[4] is None and type(pp._modules["align_layer"]) is torch.nn.Identity):
+                plist = fp[10]
+                grad = torch.is_grad_enabled() and (x.requires_grad or any(d["weight"].requires_grad or d["bias"].requires_grad for d in plist))
+                ref = fp[4]._buffers["ref_x"] if fp[4] is not None else fp[9]
+                w0 = plist[0]["weight"]
+                if not grad and w0.dtype is torch.float32 and w0.device == fp[0] and (fp[4] is None or (ref.dtype is torch.float32 and ref.device == fp[0])):
+                    return fp[8](x, fp[7], ref, [d["weight"] for d in plist], [d["bias"] for d in plist])
         assert isinstance(x, torch.Tensor), 'Input x is not a torch tensor'
         st = self._fast_state(x) if x.is_cuda else None
         if st is None or not st["fused"]:

@@ -263,8 +263,39 @@ void check_x(const at::Tensor& x, const std::vector<int64_t>& desc) {
                 x.scalar_type());
 }
 
+at::Tensor run_impl(const at::Tensor& x_in, const std::vector<int64_t>& desc, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
+                    const std::vector<at::Tensor>& biases);
+// A description registered once (molann::register_desc) and named by a small integer afterwards: what the eager modules'
+// inference calls use - converting the 30-odd integers of a description from a Python list at every call costs more
+// than the launch's own bookkeeping.  Scripted modules keep the self-contained list form (molann::run).
+std::mutex g_handle_mu;
+std::vector<std::shared_ptr<const std::vector<int64_t>>> g_handles;
+
+int64_t register_desc(std::vector<int64_t> desc) {
+    TORCH_CHECK(desc.size() >= DESC_HEAD && desc[0] == DESC_LAYOUT, "molann::register_desc: unknown descriptor layout");
+    std::lock_guard<std::mutex> lock(g_handle_mu);
+    for (size_t i = 0; i < g_handles.size(); ++i)
+        if (*g_handles[i] == desc) return (int64_t)i;
+    g_handles.push_back(std::make_shared<const std::vector<int64_t>>(std::move(desc)));
+    return (int64_t)g_handles.size() - 1;
+}
+
+at::Tensor run_h_hip(const at::Tensor& x, int64_t handle, const at::Tensor& ref_x, std::vector<at::Tensor> weights, std::vector<at::Tensor> biases) {
+    std::shared_ptr<const std::vector<int64_t>> d;
+    {
+        std::lock_guard<std::mutex> lock(g_handle_mu);
+        TORCH_CHECK(handle >= 0 && (size_t)handle < g_handles.size(), "molann::run_h: unknown handle ", handle);
+        d = g_handles[(size_t)handle];
+    }
+    return run_impl(x, *d, ref_x, weights, biases);
+}
+
 at::Tensor run_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
                    std::vector<at::Tensor> biases) {
+    return run_impl(x_in, desc, ref_x, weights, biases);
+}
+at::Tensor run_impl(const at::Tensor& x_in, const std::vector<int64_t>& desc, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
+                    const std::vector<at::Tensor>& biases) {
     check_x(x_in, desc);
     const at::Tensor x = x_in.contiguous();
     const c10::DeviceGuard guard(x.device());
@@ -349,8 +380,24 @@ std::vector<at::Tensor> run_backward_hip(const at::Tensor& x_in, std::vector<int
 // {out, grad_x}: the forward's outputs and the vector-Jacobian product for grad_out in ONE launch (molann_value_and_vjp_f32: the
 // one-pass backward that also stores the outputs).  Parameters are data.  `into` (optional: {out, grad_x} of the right shapes)
 // is written instead of fresh tensors - a caller at every MD step keeps its two buffers.
+std::vector<at::Tensor> value_and_vjp_impl(const at::Tensor& x_in, const std::vector<int64_t>& desc, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
+                                           const std::vector<at::Tensor>& biases, const at::Tensor& grad_out, const std::vector<at::Tensor>& into);
 std::vector<at::Tensor> value_and_vjp_hip(const at::Tensor& x_in, std::vector<int64_t> desc, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
                                           std::vector<at::Tensor> biases, const at::Tensor& grad_out, std::vector<at::Tensor> into) {
+    return value_and_vjp_impl(x_in, desc, ref_x, weights, biases, grad_out, into);
+}
+std::vector<at::Tensor> value_and_vjp_h_hip(const at::Tensor& x_in, int64_t handle, const at::Tensor& ref_x, std::vector<at::Tensor> weights,
+                                            std::vector<at::Tensor> biases, const at::Tensor& grad_out, std::vector<at::Tensor> into) {
+    std::shared_ptr<const std::vector<int64_t>> d;
+    {
+        std::lock_guard<std::mutex> lock(g_handle_mu);
+        TORCH_CHECK(handle >= 0 && (size_t)handle < g_handles.size(), "molann::value_and_vjp_h: unknown handle ", handle);
+        d = g_handles[(size_t)handle];
+    }
+    return value_and_vjp_impl(x_in, *d, ref_x, weights, biases, grad_out, into);
+}
+std::vector<at::Tensor> value_and_vjp_impl(const at::Tensor& x_in, const std::vector<int64_t>& desc, const at::Tensor& ref_x, const std::vector<at::Tensor>& weights,
+                                           const std::vector<at::Tensor>& biases, const at::Tensor& grad_out, const std::vector<at::Tensor>& into) {
     check_x(x_in, desc);
     TORCH_CHECK(x_in.scalar_type() == at::kFloat, "molann::value_and_vjp: float32 only");
     const at::Tensor x = x_in.contiguous();
@@ -699,6 +746,9 @@ TORCH_LIBRARY(molann, m) {
           "bool need_params) -> Tensor[]");
     m.def("run_train(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor[]");
     m.def("run_backward_mlp(Tensor feat, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out) -> Tensor");
+    m.def("register_desc(int[] desc) -> int", register_desc);
+    m.def("run_h(Tensor x, int handle, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor");
+    m.def("value_and_vjp_h(Tensor x, int handle, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, Tensor[] into) -> Tensor[]");
     m.def("value_and_vjp(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, Tensor[] into) -> Tensor[]");
     m.def("supports_backward(Tensor x, int[] desc, Tensor ref_x) -> int", supports_backward);
     m.def("launch_info(int[] desc, int device) -> str", launch_info);
@@ -716,6 +766,8 @@ TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP devic
     m.impl("run_train", run_train_hip);
     m.impl("run_backward_mlp", run_backward_mlp_hip);
     m.impl("value_and_vjp", value_and_vjp_hip);
+    m.impl("run_h", run_h_hip);
+    m.impl("value_and_vjp_h", value_and_vjp_h_hip);
 }
 
 TORCH_LIBRARY_IMPL(molann, Autograd, m) { m.impl("run", run_autograd); }
