@@ -1822,6 +1822,7 @@ struct molann_plan {
     unsigned char* d_wchain;   // weight fragments in consumption order, then the padded fp32 biases
     long chain_stream_bytes;
     int chain_fb;              // 16-frame blocks per wave
+    int chain_waves;           // waves per block: 4 (weights streamed through LDS slabs) or 8 (weight stream resident in LDS)
     char chain_note[96];
     char mlp_info[96];         // name + geometry of the last MLP kernel launch
     // large frames through frames_ring_kernel: per-frame window list, LDS positions of the alignment atoms and of the
@@ -2083,6 +2084,10 @@ std::string jit_source(const JitSpec& j) {
 }
 
 // wide bf16 MLP: layer widths, activation and frames per wave as constants
+// the whole weight stream resident in LDS (molann_mlp_jit.inc: RESIDENT): no streaming, eight waves per block
+inline bool chain_resident(const ChainGeom& g) { return g.total_frags() * 1024 <= 150 * 1024; }
+inline int chain_waves(const ChainGeom& g) { return chain_resident(g) ? 8 : 4; }
+
 std::string jit_source_chain(const ChainGeom& g, int act, int fb) {
     std::string s = "// preamble generated from the plan\n";
     char t[160];
@@ -2091,6 +2096,7 @@ std::string jit_source_chain(const ChainGeom& g, int act, int fb) {
     for (int i = 0; i <= g.nl; ++i) { snprintf(t, sizeof(t), "%s%d", i ? ", " : "", g.dims[i]); s += t; }
     s += "};\n";
     snprintf(t, sizeof(t), "constexpr int ACT = %d;\nconstexpr int FB = %d;\nconstexpr bool BF16 = %s;\n", act, fb, g.bf16 ? "true" : "false"); s += t;
+    snprintf(t, sizeof(t), "constexpr bool RESIDENT = %s;\nconstexpr int WAVES = %d;\n", chain_resident(g) ? "true" : "false", chain_waves(g)); s += t;
     s += "#line 1 \"molann_mlp_jit.inc\"\n";
     s += join_chunks(k_src_molann_mlp_jit_inc);
     return s;
@@ -2576,15 +2582,16 @@ int launch_pre(molann_plan* p, const float* x, long n_frames, float* out, int mo
 
 int launch_mlp(molann_plan* p, const float* feat, long n_frames, int in_stride, float* out, hipStream_t stream) {
     if (p->chain_fn) { // plan-specialised chain kernel: one 4-wave block per CU, 64*FB frames per block and tile
-        const long tile = 64l * p->chain_fb, n_tiles = (n_frames + tile - 1) / tile;
+        const int cw = p->chain_waves > 0 ? p->chain_waves : 4;
+        const long tile = 16l * cw * p->chain_fb, n_tiles = (n_frames + tile - 1) / tile;
         const int grid = (int)std::min<long>(n_tiles, p->num_cus);
         struct { const float* feat; float* out; const unsigned char* w; const float* b; long n; int in_stride; } ka =
             {feat, out, p->d_wchain, (const float*)(p->d_wchain + p->chain_stream_bytes), n_frames, in_stride};
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-        snprintf(p->mlp_info, sizeof(p->mlp_info), "molann_mlp_chain<%s,FB=%d> (plan-specialised) grid=%d block=256",
-                 p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->chain_fb, grid);
-        return (int)hipModuleLaunchKernel(p->chain_fn, grid, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg);
+        snprintf(p->mlp_info, sizeof(p->mlp_info), "molann_mlp_chain<%s,FB=%d%s> (plan-specialised) grid=%d block=%d",
+                 p->mlp_prec == MOLANN_MLP_BF16 ? "bf16" : "f32", p->chain_fb, cw == 8 ? ",resident" : "", grid, 64 * cw);
+        return (int)hipModuleLaunchKernel(p->chain_fn, grid, 1, 1, 64 * cw, 1, 1, 0, stream, nullptr, cfg);
     }
     MlpArgs a;
     memset(&a, 0, sizeof(a));
@@ -2889,8 +2896,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         cg.bf16 = bf16 ? 1 : 0;
         for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = p->dims[i];
         for (int fb = 4; fb >= 1 && chain_fb == 0; --fb) // upper bound; plan creation steps down while the build spills
-            if (fb * cg.regs_per_fb() <= 512) chain_fb = fb;
-        if (2 * cg.slab_max() * 1024 > 163840 - 1024) chain_fb = 0;
+            if (fb * cg.regs_per_fb() <= (chain_resident(cg) ? 256 : 512)) chain_fb = fb;     // resident: two waves per SIMD
+        if (!chain_resident(cg) && 2 * cg.slab_max() * 1024 > 163840 - 1024) chain_fb = 0;
         if (chain_fb > 0) {
             p->chain_stream_bytes = cg.total_frags() * 1024;
             chain_bytes = (size_t)p->chain_stream_bytes + (size_t)cg.bias_off(cg.nl) * 4;
@@ -2903,7 +2910,8 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
         // feature chunk handed from the preprocessing kernel to the MLP kernel: sized to stay
         // resident in the 256 MiB Infinity Cache
         long wf = (64l << 20) / ((long)d_feat * 4);
-        wf = std::max<long>(1024, std::min<long>(wf, 1l << 20)); // (narrow feature rows: few, large chunks - each costs ~6 host API calls)
+        wf = std::max<long>(1024, std::min<long>(wf, 1l << 21)); // (narrow feature rows: few, large chunks - each costs ~6 host API calls, and a
+                                                                  //  feature launch of 512 k frames takes 37 us where one of 1 M takes 46)
         wf &= ~63l;
         wf = std::max<long>(512, (wf / 2) & ~63l); // per half
         // Large frames: the feature rows are a few percent of the frame bytes, so letting them spill past the Infinity
@@ -3103,7 +3111,7 @@ int molann_plan_create(const molann_plan_desc* d, molann_plan** out_plan) {
             int scratch = 0;
             (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn);
             if (scratch > 0 && fb > 1) { (void)hipModuleUnload(mod); continue; }
-            p->chain_mod = mod; p->chain_fn = fn; p->chain_fb = fb;
+            p->chain_mod = mod; p->chain_fn = fn; p->chain_fb = fb; p->chain_waves = chain_waves(cg);
             snprintf(p->chain_note, sizeof(p->chain_note), "chain: specialised kernel, FB=%d, %zu bytes", fb, code.size());
         }
         if (!p->chain_fn) snprintf(p->chain_note, sizeof(p->chain_note), "chain: unavailable (rc=%d), mlp_mfma_kernel", rc);
@@ -3299,6 +3307,19 @@ int molann_forward_packed_f32(const molann_plan* cp, const float* x, int64_t n, 
     if (p->have_done && p->last_stream != main) HIP_TRY(hipStreamWaitEvent(main, p->ev_done, 0)); // another stream used the workspace last
     int i = 0, rc = MOLANN_OK;
     bool mlp_recorded[2] = {false, false};
+    if (n <= p->work_frames) {
+        // one chunk: nothing to overlap, so both kernels go to the caller's stream back to back - handing the chunk to the side
+        // stream and back costs two cross-stream waits (~15 us each on this stack: [6, 64, 64, 8] at 1 M frames 226 -> 196 us)
+        rc = launch_pre(p, x, (long)n, p->d_work, 0, false, main);
+        if (rc == MOLANN_OK) {
+            snprintf(info, sizeof(info), "%s", p->last_info);
+            rc = launch_mlp(p, p->d_work, (long)n, p->d_feat, out, main);
+        }
+        if (hipEventRecord(p->ev_done, main) == hipSuccess) { p->have_done = true; p->last_stream = main; }
+        if (rc != MOLANN_OK) return rc;
+        snprintf(p->last_info, sizeof(p->last_info), "%.130s || %.90s chunk=%ld", info, p->mlp_info, p->work_frames);
+        return MOLANN_OK;
+    }
     for (int64_t s = 0; s < n && rc == MOLANN_OK; s += p->work_frames, ++i) {
         const int h = i & 1;
         const long m = (long)std::min<int64_t>(p->work_frames, n - s);
@@ -3815,8 +3836,8 @@ int molann_debug_jit(const molann_plan_desc* d, int do_compile, char* buf, int c
         for (int i = 0; i <= d->n_layers; ++i) cg.dims[i] = d->layer_dims[i];
         int fb = 0;
         for (int f = 4; f >= 1 && fb == 0; --f)
-            if (f * cg.regs_per_fb() <= 400) fb = f;
-        if (fb == 0 || 2 * cg.slab_max() * 1024 > 163840 - 1024) return MOLANN_E_UNSUPPORTED;
+            if (f * cg.regs_per_fb() <= (chain_resident(cg) ? 256 : 400)) fb = f;
+        if (fb == 0 || (!chain_resident(cg) && 2 * cg.slab_max() * 1024 > 163840 - 1024)) return MOLANN_E_UNSUPPORTED;
         const std::string csrc = jit_source_chain(cg, d->activation, fb);
         if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", csrc.c_str());
         if (do_compile & 1) {
