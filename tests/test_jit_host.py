@@ -56,6 +56,7 @@ def test_code_object_cache_on_disk(tmp_path, monkeypatch):
     """MOLANN_JIT_CACHE_DIR: the second build of the same kernel is read from disk; a damaged file is rebuilt, not loaded."""
     import os
     import time
+    os.chmod(tmp_path, 0o700)
     monkeypatch.setenv("MOLANN_JIT_CACHE_DIR", str(tmp_path))
     d, keep = _desc(wl.get_workload("C2"))
     buf = ctypes.create_string_buffer(1 << 20)
@@ -63,13 +64,13 @@ def test_code_object_cache_on_disk(tmp_path, monkeypatch):
     assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
     t1 = time.perf_counter()
     files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
-    assert len(files) == 1 and open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    assert len(files) == 1 and open(os.path.join(tmp_path, files[0]), "rb").read(8) == b"MOLANNCO"    # header, then the ELF
     assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
     t2 = time.perf_counter()
     assert t2 - t1 < 0.5 * (t1 - t0)                     # no compile the second time
     open(os.path.join(tmp_path, files[0]), "wb").write(b"not a code object")
     assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
-    assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"    # rebuilt and replaced
+    assert open(os.path.join(tmp_path, files[0]), "rb").read(36)[32:] == b"\x7fELF"    # rebuilt and replaced
     d2, keep2 = _desc(wl.get_workload("C3"))              # another plan: another file
     assert _capi.lib().molann_debug_jit(ctypes.byref(d2), 1, buf, 1 << 20) > 1000
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
@@ -79,3 +80,35 @@ def test_large_frames_are_not_specialised():
     d, keep = _desc(wl.get_workload("C4"))
     rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 0, None, 0)
     assert rc == _capi.E_UNSUPPORTED
+
+
+def test_jit_cache_verifies_what_it_loads(tmp_path, monkeypatch):
+    """the on-disk code-object cache is used only from a directory of this user that nobody else can write,
+    a cached file carries its length and a hash of its contents, and one that does not verify is deleted and rebuilt."""
+    import os
+    d, keep = _desc(wl.get_workload("C2"))
+    buf = ctypes.create_string_buffer(1 << 20)
+    cache = tmp_path / "cache"
+    cache.mkdir(mode=0o700)
+    monkeypatch.setenv("MOLANN_JIT_CACHE_DIR", str(cache))
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    files = list(cache.iterdir())
+    assert len(files) == 1 and files[0].name.endswith(".hsaco")
+    blob = files[0].read_bytes()
+    assert blob[:8] == b"MOLANNCO" and blob[32:36] == b"\x7fELF"
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000          # served from the cache
+    # a flipped byte in the code object: not loaded, deleted, rebuilt
+    files[0].write_bytes(blob[:200] + bytes([blob[200] ^ 0xff]) + blob[201:])
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    assert files[0].read_bytes() == blob
+    # a truncated file
+    files[0].write_bytes(blob[:1000])
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    assert files[0].read_bytes() == blob
+    # a directory others may write is not used
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    monkeypatch.setenv("MOLANN_JIT_CACHE_DIR", str(loose))
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
+    assert list(loose.iterdir()) == []
