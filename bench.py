@@ -155,6 +155,19 @@ def visible_gpu_count(environ=None, root="/sys/class/kfd/kfd/topology/nodes"):
     return len(view)
 
 
+def core_ranges(cores):
+    """'0-15,32-47' for a set of core numbers."""
+    cs = sorted(cores)
+    out, i = [], 0
+    while i < len(cs):
+        j = i
+        while j + 1 < len(cs) and cs[j + 1] == cs[j] + 1:
+            j += 1
+        out.append("%d" % cs[i] if i == j else "%d-%d" % (cs[i], cs[j]))
+        i = j + 1
+    return ",".join(out)
+
+
 def cpu_slice(rank, n_ranks, cores=None):
     """The contiguous share of this process's allowed cores that rank `rank` of `n_ranks` pins itself to."""
     cores = sorted(os.sched_getaffinity(0)) if cores is None else sorted(cores)
@@ -486,7 +499,7 @@ def run_rank(args, side, world, rank, distributed, env=None, diagnostic=False, e
                        "dist": {"world_size": dist.get_world_size() if distributed else 1,
                                 "backend": dist.get_backend() if distributed else None,
                                 "devices": devices, "launched_by": os.environ.get("MOLANN_BENCH_LAUNCHER", "self" if not distributed else "external"),
-                                "cpu_affinity": sorted(os.sched_getaffinity(0))}},
+                                "cpu_affinity": core_ranges(os.sched_getaffinity(0))}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_frame": alg_bytes, "dense_bytes_per_frame": dense_bytes,
