@@ -205,6 +205,41 @@ def test_wide_fp32_mlp_on_small_frames(hip_device):
     assert float((got.double() - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("dims", [[6, 64, 64, 8], [6, 48, 33, 5], [6, 128, 128, 8], [6, 100, 70, 3], [6, 40, 8]])
+def test_wide_heads_run_inside_the_lane_kernel(dims, hip_device, monkeypatch):
+    """Hidden widths 33 .. 128 behind the 22-atom preprocessing: ONE launch of the lane kernel's WIDE_MLP build (the chain
+    MLP's arithmetic on a weight stream resident in LDS) - against a float64 MLP on the kernel's own features, bit for bit
+    against the two-kernel path it replaces (the same accumulation order), across batch sizes incl. ragged tiles, and with
+    live parameter updates."""
+    from molann_amd.ann import MolANN, create_sequential_nn
+    w = wl.get_workload("C3")
+    base = workload_model(w, hip_device)
+    torch.manual_seed(sum(dims))
+    nn = create_sequential_nn(dims).to(hip_device)
+    model = MolANN(base.preprocessing_layer, nn).requires_grad_(False)
+    for n in (1, 63, 64, 65, 1000, 70001):
+        x = w.make_frames(n, seed=n).to(hip_device)
+        got = _run(model, x)
+        assert "molann_lane_jit<NL=%d,wide>" % (len(dims) - 1) in last_launch_info(model), last_launch_info(model)
+        f = _run(base.preprocessing_layer, x)
+        h = f.double()
+        lins = [m for m in nn if isinstance(m, torch.nn.Linear)]
+        for i, lin in enumerate(lins):
+            h = h @ lin.weight.detach().cpu().double().T + lin.bias.detach().cpu().double()
+            if i + 1 < len(lins):
+                h = torch.tanh(h)
+        assert float((got.double() - h).abs().max()) <= 1e-5, n
+    monkeypatch.setenv("MOLANN_NO_WIDE_FUSED", "1")
+    model2 = MolANN(base.preprocessing_layer, nn).requires_grad_(False)
+    got2 = _run(model2, x)
+    assert "molann_mlp_chain<f32" in last_launch_info(model2), last_launch_info(model2)
+    assert torch.equal(got2, got)
+    monkeypatch.delenv("MOLANN_NO_WIDE_FUSED")
+    with torch.no_grad():
+        lins[-1].bias.add_(0.5)
+    assert torch.allclose(_run(model, x), got + 0.5, atol=1e-6)
+
+
 def test_cpu_tensor_and_grad_mode_fail_loudly(hip_device):
     w = wl.get_workload("C3")
     model = workload_model(w, hip_device)
@@ -367,7 +402,8 @@ def test_hip_graph_replay_of_the_two_stream_path(hip_device):
     w = wl.get_workload("C3")
     base = workload_model(w, hip_device)
     torch.manual_seed(3)
-    model = MolANN(base.preprocessing_layer, create_sequential_nn([6, 64, 64, 8]).to(hip_device)).requires_grad_(False)
+    # (a head whose weight stream does not fit LDS: narrower ones run inside the lane kernel, test_wide_heads_run_inside_the_lane_kernel)
+    model = MolANN(base.preprocessing_layer, create_sequential_nn([6, 256, 256, 8]).to(hip_device)).requires_grad_(False)
     x = w.make_frames(300000, seed=41).to(hip_device)        # more than one workspace chunk
     want = _run(model, x)
     assert "molann_mlp_chain<f32" in last_launch_info(model), last_launch_info(model)

@@ -112,3 +112,19 @@ def test_jit_cache_verifies_what_it_loads(tmp_path, monkeypatch):
     monkeypatch.setenv("MOLANN_JIT_CACHE_DIR", str(loose))
     assert _capi.lib().molann_debug_jit(ctypes.byref(d), 1, buf, 1 << 20) > 1000
     assert list(loose.iterdir()) == []
+
+
+@pytest.mark.parametrize("dims,act", [([6, 64, 64, 8], 0), ([6, 48, 33, 5], 2), ([6, 128, 128, 8], 0), ([6, 100, 70, 3], 4), ([6, 40, 8], 8), ([6, 33, 33, 33, 2], 1)])
+def test_wide_fused_forward_compiles(dims, act):
+    """The WIDE_MLP build of the lane kernel (hidden widths beyond 32: the chain MLP's arithmetic on an LDS-resident weight stream)
+    cross-compiles for gfx950 over widths, layer counts and activations; heads whose stream does not fit are refused."""
+    d, keep = _desc(wl.get_workload("C3"))
+    ld = (ctypes.c_int32 * len(dims))(*dims)
+    d.n_layers, d.layer_dims, d.activation = len(dims) - 1, ld, act
+    buf = ctypes.create_string_buffer(1 << 22)
+    rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 129, buf, 1 << 22)
+    assert rc > 1000, (rc, buf.value.decode()[:3000])
+    assert "constexpr bool WIDE_MLP = true;" in buf.value.decode()
+    big = (ctypes.c_int32 * 4)(6, 256, 256, 8)
+    d.n_layers, d.layer_dims = 3, big
+    assert _capi.lib().molann_debug_jit(ctypes.byref(d), 129, buf, 1 << 22) == _capi.E_UNSUPPORTED
