@@ -190,6 +190,7 @@ class Plan(object):
         self.n_inp = int(n_inp)
         self.n_align = int(d.n_align)
         self.n_layers = int(d.n_layers)
+        self.activation = int(activation)
         self.feature_dim = L.molann_plan_feature_dim(h)
         self.out_dim = L.molann_plan_out_dim(h)
         self.kernel_family = L.molann_plan_kernel_family(h)

@@ -178,17 +178,17 @@ class _PlanFunction(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, feat)
         ctx.entry, ctx.shapes = entry, [tuple(p.shape) for p in params]
+        ctx.with_mlp, ctx.params = with_mlp, params      # (create_graph=True: the backward is then rebuilt as a differentiable composition)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        # Grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these
-        # gradients again (the reference can, through plain autograd incl. its SVD).  The kernel's result has no graph,
-        # and `once_differentiable` would not notice either (the dependence runs through the saved x and parameters,
-        # not through grad_out) - so refuse, rather than silently drop terms of a loss built on forces.
+        # Grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these gradients
+        # again (a loss on forces; the reference can, through plain autograd incl. its SVD, ann.py:188-197).  The kernels'
+        # results carry no graph, so the gradient is rebuilt as a DIFFERENTIABLE composition: the float64 features with their
+        # double-differentiable backward (_FeatBackward64), the MLP as ATen ops on the live parameters.
         if torch.is_grad_enabled():
-            raise RuntimeError("molann_amd: the backward kernel is first-order only; create_graph=True (double "
-                               "backward, e.g. a loss on forces) is not supported")
+            return _double_backward(ctx, grad_out)
         x = ctx.saved_tensors[0]
         feat = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
         plan = ctx.entry.plan
@@ -231,17 +231,91 @@ class _PlanFunction64(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        if torch.is_grad_enabled():
-            raise RuntimeError("molann_amd: the backward kernel is first-order only; create_graph=True (double "
-                               "backward, e.g. a loss on forces) is not supported")
         (x,) = ctx.saved_tensors
         g = grad_out.contiguous()
         if g.dtype != torch.float64:
             g = g.double()
+        if torch.is_grad_enabled():          # create_graph=True: the same product, as a node that can be differentiated again
+            return _FeatBackward64.apply(x, g, ctx.entry), None
         gx = torch.empty_like(x)
         with torch.cuda.device(x.device):
             ctx.entry.plan.features_backward_f64(x, g, gx)
         return gx, None
+
+
+class _FeatBackward64(torch.autograd.Function):
+    """``gx = J(x)^T g`` of the float64 features (`molann_features_backward_f64`) as a node that can itself be differentiated -
+    what ``create_graph=True`` needs (second-order terms of a loss on forces; the reference gets them from autograd through its
+    SVD, `ann.py:188-197`).  For a cotangent ``v`` on ``gx`` its backward needs ``d/dx [v . J(x)^T g]`` and ``d/dg [v . J(x)^T g] = J(x) v``:
+    both are directional derivatives along ``v`` - of the first-order kernel's own output and of the features - taken as CENTRAL
+    DIFFERENCES of the float64 kernels, per frame with step ``h = 6e-6 * max(1, |x|_max) / |v|_max`` (the optimum for a
+    second-order formula in double: truncation ~ h^2, rounding ~ 1e-16 / h; agreement with the reference's analytic double
+    backward ~1e-9 of scale, `tests/test_gpu_backward.py::test_double_backward_*`).  Four launches; itself first-order."""
+
+    @staticmethod
+    def forward(ctx, x, g, entry):
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            entry.plan.features_backward_f64(x, g, gx)
+        ctx.save_for_backward(x, g)
+        ctx.entry = entry
+        return gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        plan = ctx.entry.plan
+        v = v.contiguous().double()
+        vmax = v.abs().amax(dim=(1, 2), keepdim=True)
+        xmax = x.abs().amax(dim=(1, 2), keepdim=True).clamp_(min=1.0)
+        h = torch.where(vmax > 0, 6e-6 * xmax / vmax.clamp(min=1e-300), torch.zeros_like(vmax))
+        xp, xm = (x + h * v).contiguous(), (x - h * v).contiguous()
+        inv = torch.where(h > 0, 0.5 / h.clamp(min=1e-300), torch.zeros_like(h))
+        gxp, gxm = torch.empty_like(x), torch.empty_like(x)
+        fp = torch.empty((x.shape[0], plan.feature_dim), dtype=torch.float64, device=x.device)
+        fm = torch.empty_like(fp)
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                plan.features_backward_f64(xp, g, gxp)
+                plan.features_backward_f64(xm, g, gxm)
+            if ctx.needs_input_grad[1]:
+                plan.features_f64(xp, fp)
+                plan.features_f64(xm, fm)
+        grad_x = (gxp - gxm) * inv if ctx.needs_input_grad[0] else None
+        grad_g = (fp - fm) * inv.view(-1, 1) if ctx.needs_input_grad[1] else None
+        return grad_x, grad_g, None
+
+
+_ACT_FNS = {
+    _capi.ACT_TANH: torch.tanh, _capi.ACT_RELU: torch.relu, _capi.ACT_SIGMOID: torch.sigmoid, _capi.ACT_IDENTITY: (lambda t: t),
+    _capi.ACT_ELU: torch.nn.functional.elu, _capi.ACT_SILU: torch.nn.functional.silu, _capi.ACT_SOFTPLUS: torch.nn.functional.softplus,
+    _capi.ACT_LEAKY_RELU: torch.nn.functional.leaky_relu, _capi.ACT_GELU: torch.nn.functional.gelu,
+}
+
+
+def _double_backward(ctx, grad_out):
+    """The gradients of a `_PlanFunction` node as a differentiable composition (create_graph=True): features in float64 through
+    `_PlanFunction64` (whose backward is `_FeatBackward64`), the MLP as ATen ops on the live parameters, `torch.autograd.grad`
+    with ``create_graph=True`` over it."""
+    x = ctx.saved_tensors[0]
+    entry, params = ctx.entry, list(ctx.params)
+    with torch.enable_grad():
+        y = _PlanFunction64.apply(x.double(), entry).to(x.dtype)
+        if ctx.with_mlp:
+            act = _ACT_FNS[entry.plan.activation]
+            n = len(params) // 2
+            for l in range(n):
+                y = torch.nn.functional.linear(y, params[2 * l], params[2 * l + 1])
+                if l + 1 < n:
+                    y = act(y)
+        wanted = [(0, x)] if ctx.needs_input_grad[0] else []
+        wanted += [(3 + i, p) for i, p in enumerate(params) if ctx.needs_input_grad[3 + i]]
+        got = torch.autograd.grad(y, [t for _, t in wanted], grad_out, create_graph=True, allow_unused=True) if wanted else ()
+    out = [None] * (3 + len(params))
+    for (i, _), gi in zip(wanted, got):
+        out[i] = gi
+    return tuple(out)
 
 
 def _device_buffer(ref_x, x):

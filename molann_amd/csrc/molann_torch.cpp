@@ -29,6 +29,7 @@
 
 #include <torch/library.h>
 #include <torch/csrc/autograd/custom_function.h>
+#include <torch/csrc/autograd/autograd.h>
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
@@ -595,6 +596,88 @@ at::Tensor call_run_backward_mlp(const at::Tensor& feat, const std::vector<int64
     return op.call(feat, desc, ref_x, weights, biases, grad_out);
 }
 
+std::vector<int64_t> features_only(const std::vector<int64_t>& desc);
+at::Tensor activation(int64_t code, const at::Tensor& t);
+
+// ---- create_graph=True (round 3) ---------------------------------------------------------------------------------------------
+// The kernels' gradients carry no graph.  When a backward runs under an enabled grad mode (the caller wants to differentiate the
+// gradients again: a loss on forces; the reference gets that from autograd through its SVD, ann.py:188-197) the gradient is
+// rebuilt as a DIFFERENTIABLE composition: the float64 features as a node (Features64Fn) whose backward - J(x)^T g, the float64
+// kernel - is itself a node (FeatBackward64Fn) with a backward of its own, and the MLP as ATen ops on the live parameters.
+// FeatBackward64Fn's backward needs, for a cotangent v on J^T g, d/dx [v . J(x)^T g] and d/dg [..] = J(x) v: directional
+// derivatives along v of the first-order kernel's output and of the features, taken as central differences of the float64
+// kernels, per frame with h = 6e-6 max(1, |x|_max) / |v|_max (molann_amd/ann.py: _FeatBackward64 is the same in Python).
+struct FeatBackward64Fn : public torch::autograd::Function<FeatBackward64Fn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& g, std::vector<int64_t> desc,
+                              const at::Tensor& ref_x) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        ctx->save_for_backward({x, g, ref_x});
+        ctx->saved_data["desc"] = desc;
+        return call_run_backward(x, desc, ref_x, {}, {}, g, true, false)[0];
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        TORCH_CHECK(!at::GradMode::is_enabled(), "molann::run: gradients of order three are not available (the double backward is first-order itself)");
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &x = saved[0], &g = saved[1], &ref_x = saved[2];
+        const std::vector<int64_t> desc = ctx->saved_data["desc"].toIntVector();
+        at::AutoDispatchBelowADInplaceOrView below;
+        const at::Tensor v = grad_outputs[0].to(at::kDouble).contiguous();
+        const at::Tensor vmax = v.abs().amax({1, 2}, true), xmax = x.abs().amax({1, 2}, true).clamp_min(1.0);
+        const at::Tensor h = at::where(vmax > 0, 6e-6 * xmax / vmax.clamp_min(1e-300), at::zeros_like(vmax));
+        const at::Tensor inv = at::where(h > 0, 0.5 / h.clamp_min(1e-300), at::zeros_like(h));
+        const at::Tensor xp = (x + h * v).contiguous(), xm = (x - h * v).contiguous();
+        at::Tensor gx, gg;
+        if (ctx->needs_input_grad(0))
+            gx = (call_run_backward(xp, desc, ref_x, {}, {}, g, true, false)[0] - call_run_backward(xm, desc, ref_x, {}, {}, g, true, false)[0]) * inv;
+        if (ctx->needs_input_grad(1))
+            gg = (call_run(xp, desc, ref_x, {}, {}) - call_run(xm, desc, ref_x, {}, {})) * inv.view({-1, 1});
+        return {gx, gg, at::Tensor(), at::Tensor()};
+    }
+};
+
+struct Features64Fn : public torch::autograd::Function<Features64Fn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        ctx->save_for_backward({x, ref_x});
+        ctx->saved_data["desc"] = desc;
+        return call_run(x, desc, ref_x, {}, {});
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        const std::vector<int64_t> desc = ctx->saved_data["desc"].toIntVector();
+        const at::Tensor g = grad_outputs[0].to(at::kDouble).contiguous();
+        if (at::GradMode::is_enabled()) return {FeatBackward64Fn::apply(saved[0], g, desc, saved[1]), at::Tensor(), at::Tensor()};
+        at::AutoDispatchBelowADInplaceOrView below;
+        return {call_run_backward(saved[0], desc, saved[1], {}, {}, g, true, false)[0], at::Tensor(), at::Tensor()};
+    }
+};
+
+// the gradients of a RunFunction node as a differentiable composition: [x, ref_x, weights..., biases...]
+torch::autograd::variable_list double_backward(const at::Tensor& x, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                                               const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases,
+                                               const at::Tensor& grad_out, const std::vector<bool>& need) {
+    const int64_t nl = (int64_t)weights.size();
+    const std::vector<int64_t> fdesc = desc[1] == KIND_FORWARD ? features_only(desc) : (desc[1] == KIND_ALIGN ? align_as_features(desc) : desc);
+    const at::Tensor ref64 = ref_x.numel() > 0 ? ref_x.detach().to(at::kDouble) : ref_x;
+    at::Tensor h = Features64Fn::apply(x.to(at::kDouble), fdesc, ref64).to(x.scalar_type());
+    if (desc[1] == KIND_ALIGN) h = h.view_as(x);
+    if (desc[1] == KIND_FORWARD)
+        for (int64_t l = 0; l < nl; ++l) {
+            h = at::linear(h, weights[l], biases[l]);
+            if (l + 1 < nl) h = activation(desc[7], h);
+        }
+    std::vector<at::Tensor> inputs;
+    std::vector<int64_t> where;
+    if (need[0]) { inputs.push_back(x); where.push_back(0); }
+    for (int64_t l = 0; l < nl; ++l) if (need[2 + l]) { inputs.push_back(weights[l]); where.push_back(3 + l); }
+    for (int64_t l = 0; l < nl; ++l) if (need[2 + nl + l]) { inputs.push_back(biases[l]); where.push_back(3 + nl + l); }
+    torch::autograd::variable_list out(3 + 2 * nl);
+    if (inputs.empty()) return out;
+    const auto got = torch::autograd::grad({h}, inputs, {grad_out.to(h.scalar_type())}, /*retain_graph=*/true, /*create_graph=*/true, /*allow_unused=*/true);
+    for (size_t i = 0; i < got.size(); ++i) out[where[i]] = got[i];
+    return out;
+}
+
 // forward = one launch of the plan, nothing but the inputs saved; backward = molann_backward_f32, which
 // recomputes the forward per frame (first-order only: the backward is not itself differentiable)
 struct RunFunction : public torch::autograd::Function<RunFunction> {
@@ -625,12 +708,17 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
-        // grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these
-        // gradients again (the reference can, through plain autograd).  molann_backward_f32 is a kernel, its result has
-        // no graph: refusing is the only honest answer - silently returning constants would drop terms of a loss.
-        TORCH_CHECK(!at::GradMode::is_enabled(),
-                    "molann::run: the backward kernel is first-order only; create_graph=True (double backward, e.g. a loss on "
-                    "forces) is not supported");
+        // grad mode is on inside a backward only under create_graph=True: the caller wants to differentiate these gradients
+        // again.  molann_backward_f32 is a kernel, its result has no graph: the gradient is then rebuilt as a differentiable
+        // composition (double_backward above).
+        if (at::GradMode::is_enabled()) {
+            const auto sv = ctx->get_saved_variables();
+            const int64_t n = ctx->saved_data["n_layers"].toInt();
+            std::vector<at::Tensor> w(sv.begin() + 2, sv.begin() + 2 + n), b(sv.begin() + 2 + n, sv.begin() + 2 + 2 * n);
+            std::vector<bool> need(2 + 2 * n);
+            for (int64_t i = 0; i < 2 + 2 * n; ++i) need[(size_t)i] = ctx->needs_input_grad((size_t)i);
+            return double_backward(sv[0], ctx->saved_data["desc"].toIntVector(), sv[1], w, b, grad_outputs[0], need);
+        }
         const auto saved = ctx->get_saved_variables();
         const std::vector<int64_t> desc = ctx->saved_data["desc"].toIntVector();
         const int64_t nl = ctx->saved_data["n_layers"].toInt();

@@ -376,6 +376,43 @@ def main():
     print(json.dumps(meta, indent=1))
 
 
+def grad2_case(name, u, x, input_numbers, features, align, mlp_dims, use_angle_value=False, seed=13):
+    """Second-order golden vectors from the REFERENCE's autograd: E = sum(out * G), forces F = dE/dx with create_graph=True,
+    L = sum(F * F); stored: dL/dx and dL/d(parameters) (float64 model; the float32 model's dL/dx as well)."""
+    import copy
+    input_ag, feats, flayer, alayer, nn = build_reference_model(u, input_numbers, list(features), align, mlp_dims, use_angle_value)
+    model = MolANN(PreprocessingANN(alayer, flayer), nn) if nn is not None else PreprocessingANN(alayer, flayer)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    rec = {}
+    G = None
+    for tag, m, xx in (("f32", model, x.clone()), ("f64", copy.deepcopy(model).double(), x.double())):
+        xx.requires_grad_(True)
+        out = m(xx)
+        if G is None:
+            G = torch.randn(out.shape, generator=g)
+        (F,) = torch.autograd.grad((out * G.to(out.dtype)).sum(), xx, create_graph=True)
+        L = (F * F).sum()
+        L.backward()
+        rec["F_" + tag] = F.detach().numpy()
+        rec["gx2_" + tag] = xx.grad.numpy()
+        for i, prm in enumerate(m.parameters()):
+            rec["gp2_%d_%s" % (i, tag)] = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).numpy()   # (the forces do not depend on the last bias)
+    rec.update(x=x.numpy(), G=G.numpy(), n_inp=np.int64(len(input_ag)), use_angle_value=np.bool_(use_angle_value),
+               feat_types=np.asarray([t for t, _ in features], dtype=np.int64))
+    flat, ptr = csr([a for _, a in features])
+    rec["feat_numbers"], rec["feat_ptr"] = flat, ptr
+    if align is not None:
+        rec["align_numbers"] = np.asarray(align, dtype=np.int64)
+    if nn is not None:
+        rec["mlp_dims"] = np.asarray(mlp_dims, dtype=np.int64)
+        for i, lin in enumerate([m_ for m_ in nn if isinstance(m_, torch.nn.Linear)]):
+            rec["W%d" % i] = lin.weight.detach().numpy()
+            rec["b%d" % i] = lin.bias.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("%-24s gx2 %s  max|gx2_32-gx2_64| = %.3g of %.3g" % (name, rec["gx2_f64"].shape, np.abs(rec["gx2_f32"] - rec["gx2_f64"]).max(), np.abs(rec["gx2_f64"]).max()))
+
+
 def round3_main():
     """Round 3 additions only (the other files are left untouched): AlignmentLayer.forward on large frames - the 5000-atom
     chain of workload A4 (x regenerated from the seed) and a 301-atom chain whose frame is not a multiple of 16 bytes - and
@@ -395,6 +432,13 @@ def round3_main():
     w3 = wl.get_workload("C3")
     run_case("molann_C3_wide64", u, w3.make_frames(512, seed=64), list(range(1, 23)), w3.features, align=w3.align, mlp_dims=[6, 64, 64, 8])
     run_case("molann_C3_wide48", u, w3.make_frames(300, seed=48), list(range(1, 23)), w3.features, align=w3.align, mlp_dims=[6, 48, 33, 5])
+    # second-order gradients (create_graph=True): the reference's autograd through its SVD (files grad2_*.npz)
+    all22 = list(range(1, 23))
+    grad2_case("grad2_molann_C3", u, w3.make_frames(48, seed=31), all22, w3.features, w3.align, w3.mlp_dims)
+    wp = wl.get_workload("C3p")
+    grad2_case("grad2_features_C3p", u, wp.make_frames(48, seed=32), all22, wp.features, wp.align, None)
+    w2 = wl.get_workload("C2")
+    grad2_case("grad2_features_C2", u, w2.make_frames(48, seed=33), all22, w2.features, None, None)
 
 
 if __name__ == "__main__":

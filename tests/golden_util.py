@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names(prefix=""):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if n != "ala_dipeptide_pdb" and not n.startswith("grad_")]   # grad_*: test_gpu_backward.py
+    return [n for n in names if n != "ala_dipeptide_pdb" and not n.startswith("grad_") and not n.startswith("grad2_")]   # grad_* / grad2_*: test_gpu_backward.py
 
 
 def load_meta():

@@ -533,3 +533,42 @@ def test_value_and_vjp_latency_and_jacobian(hip_device):
     for k in range(d_out):
         (gk,) = torch.autograd.grad(ye[0, k], xe, retain_graph=True)
         assert float((J[k] - gk[0]).abs().max()) <= 1e-6 * max(1.0, float(gk.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["grad2_molann_C3", "grad2_features_C3p", "grad2_features_C2"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "scripted"])
+def test_double_backward_matches_reference_autograd(name, dtype, hip_device):
+    """create_graph=True (round 3): a loss on forces.  E = sum(model(x) * G), F = dE/dx with create_graph=True, L = sum(F * F);
+    dL/dx and dL/d(parameters) against the REFERENCE's autograd through its SVD (tests/golden/grad2_*.npz, written by
+    oracle/gen_golden.py --round3).  The second-order terms are central differences of the float64 kernels along the cotangent
+    (molann_amd/ann.py: _FeatBackward64; csrc/molann_torch.cpp: FeatBackward64Fn): 1e-6 of scale in float64, and no further from
+    the float64 reference than a few times the reference's own float32 run in float32.  Eager float32 (the operator's autograd
+    node), eager float64 (the Python functions) and a scripted model."""
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    model = _model_from_golden(d, hip_device)
+    x = torch.from_numpy(d["x"]).to(hip_device)
+    G = torch.from_numpy(d["G"]).to(hip_device)
+    if dtype == "float64":
+        model, x, G = model.double(), x.double(), G.double()
+    run = torch.jit.script(model) if dtype == "scripted" else model
+    x.requires_grad_(True)
+    out = run(x)
+    (F,) = torch.autograd.grad((out * G).sum(), x, create_graph=True)
+    assert F.requires_grad
+    L = (F * F).sum()
+    L.backward()
+    torch.cuda.synchronize()
+    scale_f = max(1e-3, float(np.abs(d["F_f64"]).max()))
+    assert float(np.abs(F.detach().cpu().numpy().astype(np.float64) - d["F_f64"]).max()) <= (1e-9 if dtype == "float64" else 1e-4) * scale_f
+    def close(got, key):
+        ref64, ref32 = d[key + "_f64"], d[key + "_f32"]
+        scale = max(1e-3, float(np.abs(ref64).max()))
+        err = float(np.abs(got.astype(np.float64) - ref64).max())
+        own = float(np.abs(ref32.astype(np.float64) - ref64).max())
+        bound = 1e-6 * scale if dtype == "float64" else max(2e-4 * scale, 4.0 * own)
+        assert err <= bound, (key, err, own, scale)
+    close(x.grad.cpu().numpy(), "gx2")
+    params = list(model.parameters())
+    for i, p in enumerate(params):
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+        close(got, "gp2_%d" % i)
