@@ -156,10 +156,10 @@ def test_double_backward_gives_a_graph_and_third_order_is_refused(hip_device):
         y = m(x)
         (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
         assert gx.requires_grad
-        (g2,) = torch.autograd.grad((gx * gx).sum(), x, create_graph=True)
+        (g2,) = torch.autograd.grad((gx * gx).sum(), x, retain_graph=True)
         assert torch.isfinite(g2).all()
-        with pytest.raises(RuntimeError):
-            torch.autograd.grad(g2.sum(), x)
+        with pytest.raises(RuntimeError):                  # a graph for the second-order gradients = third order: refused
+            torch.autograd.grad((gx * gx).sum(), x, create_graph=True)
         (gx1,) = torch.autograd.grad(m(x).sum(), x)       # first order still fine afterwards
         assert torch.isfinite(gx1).all() and float((gx1 - gx.detach()).abs().max()) <= 1e-4 * max(1.0, float(gx1.abs().max()))
 
