@@ -209,7 +209,23 @@ def _a4():
                     description="5000-atom chain, AlignmentLayer.forward alone (Kabsch on 312 'CA', all 5000 atoms written back)")
 
 
-_FACTORIES = {"A3": _a3, "A4": _a4, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
+def _peptide_xyz():
+    return synthetic_chain(n_atoms=166, step=1.4, seed=11)
+
+
+def _p1():
+    # the size class between the two BASELINE systems: a 166-atom peptide (chignolin's size), Kabsch on every fourth atom
+    feats = [(DIHEDRAL, tuple(range(s, s + 4))) for s in range(5, 160, 20)]
+    return Workload("P1", _peptide_xyz(), feats, align=tuple(range(2, 167, 4)), mlp_dims=[16, 32, 8], frames=1 << 20,
+                    rigid_motion=True, description="166-atom chain, Kabsch on 42 atoms + 8 dihedrals (d=16) + MLP [16,32,8]")
+
+
+def _a5():
+    return Workload("A5", _peptide_xyz(), [], align=tuple(range(2, 167, 4)), frames=1 << 20, rigid_motion=True, kind="align",
+                    description="166-atom chain, AlignmentLayer.forward alone (Kabsch on 42 atoms, all 166 atoms written back)")
+
+
+_FACTORIES = {"A3": _a3, "A4": _a4, "A5": _a5, "P1": _p1, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
 
 
 def get_workload(name):
