@@ -28,9 +28,10 @@ def _oracle_rows(w, model, xs):
 
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 1000, 2048 * 8 + 3, 70001])
 def test_peptide_frames_batched_solve(n, hip_device, monkeypatch):
-    """P1 (166 atoms, Kabsch on 42, 8 dihedrals, MLP [16,32,8]): eight frames per ring entry; features bit for bit against one
-    frame per entry (MOLANN_RING_BATCH=1) and against frames_wave_kernel (the same per-frame arithmetic), features and outputs
-    within 1e-5 of the float64 oracle; batch sizes around the entry size, a short last entry, rings that wrap."""
+    """P1 (166 atoms, Kabsch on 42, 8 dihedrals, MLP [16,32,8]): eight frames per ring entry (eight lanes per frame); features
+    against one frame per entry (MOLANN_RING_BATCH=1) and against frames_wave_kernel within 2e-6 (the covariance sums are taken
+    in another order: the last bits of the centroid differ), those two bit for bit, features and outputs within 1e-5 of the
+    float64 oracle; batch sizes around the entry size, a short last entry, rings that wrap."""
     w = wl.get_workload("P1")
     model = workload_model(w, hip_device).requires_grad_(False)
     pp = model.preprocessing_layer
@@ -51,8 +52,8 @@ def test_peptide_frames_batched_solve(n, hip_device, monkeypatch):
         fw = pp(x)
         assert "frames_wave_kernel" in last_launch_info(pp)
     torch.cuda.synchronize()
-    assert torch.equal(f8, f1)
-    assert torch.equal(f8, fw)
+    assert torch.equal(f1, fw)
+    assert float((f8 - fw).abs().max()) <= 2e-6
     idx = torch.unique(torch.cat([torch.arange(0, min(n, 24)), torch.arange(max(0, n - 24), n),
                                   torch.from_numpy(np.random.default_rng(1).integers(0, n, size=200))]))
     want_f, want_y = _oracle_rows(w, model, x[idx.to(hip_device)].cpu())
@@ -66,7 +67,7 @@ def test_peptide_frames_batched_solve(n, hip_device, monkeypatch):
                                                        (400, 380, 10, "ND=6>")])
 def test_entry_sizes(n_inp, n_align, n_feat, want, hip_device, monkeypatch):
     """The other entry sizes (4 frames of up to 128 windows, 2 of up to 256, 1 beyond) on chains with large alignment sets, against
-    frames_wave_kernel bit for bit and the float64 oracle within 1e-5."""
+    frames_wave_kernel (within 2e-6 of the features' scale; bit for bit with one frame per entry) and the float64 oracle within 1e-5."""
     from test_gpu_large_batches import _chain_plan
     xyz, feats, al, model = _chain_plan(n_inp, n_feat, n_align, [16, 4], hip_device, n_inp + n_align)
     pp = model.preprocessing_layer
@@ -81,7 +82,10 @@ def test_entry_sizes(n_inp, n_align, n_feat, want, hip_device, monkeypatch):
     with torch.no_grad():
         fw = pp(x)
     torch.cuda.synchronize()
-    assert torch.equal(f, fw)
+    if "B=" in info:
+        assert float((f - fw).abs().max()) <= 2e-6 * max(1.0, float(fw.abs().max()))
+    else:
+        assert torch.equal(f, fw)
     ref_x = mo.center_reference(torch.from_numpy(xyz[al])).double()
     want_f = mo.preprocessing_forward(x[:256].cpu().double(), feats, False, al, ref_x)
     assert float((f[:256].cpu().double() - want_f).abs().max()) <= 1e-5 * max(1.0, float(want_f.abs().max()))

@@ -240,7 +240,7 @@ def test_random_large_frame_plans_through_the_ring_kernel(seed, hip_device, monk
     random frame sizes, touched-atom counts from a handful to > 2048 windows (where the plan falls back to
     frames_wave_kernel), alignment sets, item mixes incl. positions at both ends of the frame, and batch sizes around
     the ring's and the grid's sizes (1 frame, fewer frames than CUs, many frames per block) - against the fp64 oracle,
-    and bit for bit against frames_wave_kernel on the same plan."""
+    and against frames_wave_kernel on the same plan (bit for bit with one frame per ring entry, within 2e-6 with several)."""
     rng = np.random.default_rng(1000 + seed)
     n_inp = int(rng.choice([120, 333, 1000, 2500, 5000]))
     xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
@@ -274,4 +274,7 @@ def test_random_large_frame_plans_through_the_ring_kernel(seed, hip_device, monk
         with torch.no_grad():
             old = pp(x.to(hip_device)).cpu()
         assert "frames_wave_kernel" in last_launch_info(pp)
-        assert torch.equal(old, got)          # the same per-frame arithmetic on the same values
+        if "B=" in info:                      # several frames per entry: the covariance sums are taken in another order
+            assert float((old - got).abs().max()) <= 2e-6 * scale, info
+        else:
+            assert torch.equal(old, got)      # the same per-frame arithmetic on the same values
