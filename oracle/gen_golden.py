@@ -441,7 +441,30 @@ def round3_main():
     grad2_case("grad2_features_C2", u, w2.make_frames(48, seed=33), all22, w2.features, None, None)
 
 
+def round3b_main():
+    """Round 3, second batch (the other files are left untouched): frames between the two BASELINE systems - workload P1 (166-atom
+    chain, Kabsch on 42 atoms, 8 dihedrals, MLP [16, 32, 8]; 99 frames: a short last ring entry), its AlignmentLayer alone (A5) and a
+    300-atom chain aligned on 200 atoms (two frames per ring entry)."""
+    os.makedirs(OUT, exist_ok=True)
+    w = wl.get_workload("P1")
+    u = Universe(w.ref_xyz)
+    alln = list(range(1, w.n_atoms + 1))
+    run_case("molann_P1", u, w.make_frames(99, seed=5), alln, w.features, align=list(w.align), mlp_dims=w.mlp_dims,
+             extra={"ref_xyz": w.ref_xyz})
+    run_case("align_P1", u, w.make_frames(41, seed=6), alln, align=list(w.align), kind="align", extra={"ref_xyz": w.ref_xyz})
+    xyz = wl.synthetic_chain(n_atoms=300, step=1.4, seed=13)
+    u3 = Universe(xyz)
+    rng = np.random.default_rng(8)
+    align = sorted((rng.choice(300, size=200, replace=False) + 1).tolist())
+    feats = wl.chain_features(300, 30, 9)
+    run_case("molann_chain300", u3, noisy(xyz, 51, 0.1, 300, rigid=True), list(range(1, 301)), feats, align=align,
+             mlp_dims=[sum(1 if t in (wl.BOND, wl.ANGLE) else 2 for t, _ in feats), 32, 8], extra={"ref_xyz": xyz})
+
+
 if __name__ == "__main__":
+    if "--round3b" in sys.argv:
+        round3b_main()
+        sys.exit(0)
     if "--round3" in sys.argv:
         round3_main()
         sys.exit(0)

@@ -199,10 +199,11 @@ def test_bf16_mlp_error_is_measured(hip_device):
 BF16_BOUND = 2.5e-3   # measured on MI355X (round 3): 1.18e-3 at output scale 0.35, and 4.5e-8 against the arithmetic model
 
 
-@pytest.mark.parametrize("n_inp", [86, 100, 301, 1000, 1537, 2503, 5000, 6570, 12288, 12400])
+@pytest.mark.parametrize("n_inp", [86, 100, 166, 301, 384, 385, 769, 1000, 1537, 2503, 5000, 6570, 12288, 12400])
 def test_large_frame_alignment_in_registers(n_inp, hip_device, monkeypatch):
-    """AlignmentLayer.forward beyond the lane kernel's frame sizes: frames_align_regs_kernel (the frame held in the registers of a
-    block of 1, 2, 4 or 8 data waves + a solver wave) up to 12 288 atoms, frames_wave_kernel beyond.  Frame sizes that are /
+    """AlignmentLayer.forward beyond the lane kernel's frame sizes: frames_align_batch_kernel up to 384 atoms (rounds of 16 / 8 / 4
+    consecutive frames, one rotation solve per round; batch sizes that leave a short last round), frames_align_regs_kernel (the
+    frame held in the registers of a block of 1, 2, 4 or 8 data waves + a solver wave) up to 12 288 atoms, frames_wave_kernel beyond.  Frame sizes that are /
     are not multiples of 16 bytes, alignment sets of 3 .. 400 atoms, batches around the grid's size; against the float64
     oracle and against the gather kernel (MOLANN_NO_RING=1)."""
     rng = np.random.default_rng(n_inp)
@@ -223,7 +224,8 @@ def test_large_frame_alignment_in_registers(n_inp, hip_device, monkeypatch):
         with torch.no_grad():
             got = al(xd)
         info = last_launch_info(al)
-        assert ("frames_align_regs_kernel" in info) == (n_inp <= 12288), info
+        assert ("frames_align_batch_kernel" in info) == (n_inp <= 384), info
+        assert ("frames_align_regs_kernel" in info) == (384 < n_inp <= 12288), info
         want = mo.align_forward(x.double(), align, ref_x)
         own = float((mo.align_forward(x, align, ref_x.float()).double() - want).abs().max())     # the reference's arithmetic in fp32
         err = float((got.cpu().double() - want).abs().max())
