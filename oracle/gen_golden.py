@@ -150,7 +150,7 @@ def noisy(ref_xyz, n, sigma, seed, rigid=False, translation=3.0, reflect_every=0
     return x
 
 
-def grad_case(name, u, x, input_numbers, features, align, mlp_dims, use_angle_value=False, seed=11):
+def grad_case(name, u, x, input_numbers, features, align, mlp_dims, use_angle_value=False, seed=11, extra=None):
     """Gradients of sum(out * G) from the REFERENCE's autograd (fp32 and its .double() copy)."""
     import copy
     input_ag, feats, flayer, alayer, nn = build_reference_model(u, input_numbers, list(features), align, mlp_dims, use_angle_value)
@@ -180,6 +180,8 @@ def grad_case(name, u, x, input_numbers, features, align, mlp_dims, use_angle_va
         for i, lin in enumerate([m for m in nn if isinstance(m, torch.nn.Linear)]):
             rec["W%d" % i] = lin.weight.detach().numpy()
             rec["b%d" % i] = lin.bias.detach().numpy()
+    if extra:
+        rec.update(extra)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
     print("%-24s gx %s  max|gx32-gx64| = %.3g" % (name, rec["gx_f32"].shape, np.abs(rec["gx_f32"] - rec["gx_f64"]).max()))
 
@@ -461,7 +463,21 @@ def round3b_main():
              mlp_dims=[sum(1 if t in (wl.BOND, wl.ANGLE) else 2 for t, _ in feats), 32, 8], extra={"ref_xyz": xyz})
 
 
+def round3c_main():
+    """Round 3, third batch: gradients (the reference's autograd, fp32 and fp64) of the mid-size model P1 - the training path of a
+    small head behind the wave-per-frame kernels - and of its features alone."""
+    os.makedirs(OUT, exist_ok=True)
+    w = wl.get_workload("P1")
+    u = Universe(w.ref_xyz)
+    alln = list(range(1, w.n_atoms + 1))
+    grad_case("grad_molann_P1", u, w.make_frames(70, seed=21), alln, w.features, list(w.align), w.mlp_dims, extra={"ref_xyz": w.ref_xyz})
+    grad_case("grad_features_P1", u, w.make_frames(33, seed=22), alln, w.features, list(w.align), None, extra={"ref_xyz": w.ref_xyz})
+
+
 if __name__ == "__main__":
+    if "--round3c" in sys.argv:
+        round3c_main()
+        sys.exit(0)
     if "--round3b" in sys.argv:
         round3b_main()
         sys.exit(0)

@@ -20,6 +20,7 @@ U = Universe(wl.ALA_DIPEPTIDE_XYZ)
 
 
 def _model_from_golden(d, dev):
+    U = Universe(d["ref_xyz"]) if "ref_xyz" in d else globals()["U"]       # a system of its own (the 166-atom chain of P1)
     ptr = d["feat_ptr"]
     feats = [Feature("f%d" % i, wl.TYPE_NAMES[int(t)], U.atoms_by_number(d["feat_numbers"][ptr[i]:ptr[i + 1]].tolist()))
              for i, t in enumerate(d["feat_types"].tolist())]
@@ -46,7 +47,7 @@ def _close(got, ref32, ref64, what):
 
 
 @pytest.mark.parametrize("name", ["grad_molann_C1", "grad_molann_C3", "grad_features_C2", "grad_features_C3_val",
-                                  "grad_features_C3p"])
+                                  "grad_features_C3p", "grad_molann_P1", "grad_features_P1"])
 def test_gradients_match_reference_autograd(name, hip_device):
     d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     model = _model_from_golden(d, hip_device)
@@ -572,3 +573,37 @@ def test_double_backward_matches_reference_autograd(name, dtype, hip_device):
     for i, p in enumerate(params):
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
         close(got, "gp2_%d" % i)
+
+
+def test_small_head_behind_wave_per_frame_kernels_trains_through_the_hip_kernels(hip_device):
+    """P1 (166 atoms: the features come from frames_ring_kernel, the head [16,32,8] from mlp_lane_kernel): requires_grad goes
+    through the plan's own backward - the kept features, molann_mlp_bwd on the matrix cores and the wave-per-frame
+    preprocessing backward - not through torch's Linear layers; gradients against torch autograd of the float64 oracle."""
+    from molann_amd.ann import last_launch_info
+    w = wl.get_workload("P1")
+    model = wl.build_model(w, hip_device)
+    n = 3000
+    x = w.make_frames(n, seed=4).to(hip_device).requires_grad_(True)
+    out = model(x)
+    assert "frames_ring_kernel" in last_launch_info(model) and "mlp_lane_kernel" in last_launch_info(model), last_launch_info(model)
+    G = torch.randn(n, w.out_dim(), generator=torch.Generator().manual_seed(1)).to(hip_device)
+    (out * G).sum().backward()
+    info = last_launch_info(model)
+    assert "frames_wave_bwd" in info, info
+    st = model._fast_state(x)
+    assert st["entry"]().plan.backward_kind() == 1
+    lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
+    xx = x.detach().cpu().double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    feats = [(t, [a - 1 for a in atoms]) for t, atoms in w.features]
+    al = [a - 1 for a in w.align]
+    ref_x = mo.center_reference(torch.from_numpy(w.ref_xyz[al])).double()
+    want = mo.molann_forward(xx, feats, ws, bs, w.use_angle_value, al, ref_x)
+    (want * G.cpu().double()).sum().backward()
+    assert float((out.detach().cpu().double() - want.detach()).abs().max()) <= 1e-5
+    sx = float(xx.grad.abs().max())
+    assert float((x.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * sx
+    for lin, wr, br in zip(lins, ws, bs):
+        assert float((lin.weight.grad.cpu().double() - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
+        assert float((lin.bias.grad.cpu().double() - br.grad).abs().max()) <= 2e-4 * max(1.0, float(br.grad.abs().max()))
