@@ -589,7 +589,7 @@ def test_small_head_behind_wave_per_frame_kernels_trains_through_the_hip_kernels
     G = torch.randn(n, w.out_dim(), generator=torch.Generator().manual_seed(1)).to(hip_device)
     (out * G).sum().backward()
     info = last_launch_info(model)
-    assert "frames_wave_bwd" in info, info
+    assert "frames_group_bwd_kernel<B=8>" in info, info
     st = model._fast_state(x)
     assert st["entry"]().plan.backward_kind() == 1
     lins = [m for m in model.ann_layers if isinstance(m, torch.nn.Linear)]
