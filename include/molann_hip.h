@@ -208,9 +208,11 @@ int molann_plan_backward_kind(molann_plan* plan);
  * its first backward), molann_mlp_backward_f32 and molann_features_backward_f32 - and a caller that kept the features
  * of its forward (molann_forward_train_f32) calls those two itself and saves the recompute.
  * Available for plans served by the lane-per-frame kernel with the MLP fused (or no MLP) and tanh / ReLU /
- * sigmoid / identity / SiLU / LeakyReLU (kernels compiled with hipRTC at the first call), and for feature
- * plans without an MLP on large frames (one wave per frame, float atomics into the zeroed gradient row);
- * otherwise MOLANN_E_UNSUPPORTED. */
+ * sigmoid / identity / SiLU / LeakyReLU (kernels compiled with hipRTC at the first call); for feature
+ * plans without an MLP on large frames (one wave per frame; frames up to 1024 atoms with an alignment: eight / four / two
+ * frames per wave and round); and for large-frame plans whose MLP is within the fused MLP's limits (every width and the
+ * feature dim <= 32, <= 4 layers, the activations above): the three launches, the features recomputed by the plan's
+ * forward kernel; otherwise MOLANN_E_UNSUPPORTED. */
 int molann_backward_f32(molann_plan* plan, const float* x, const float* grad_out, int64_t n_frames, float* grad_x,
                         float* grad_params, molann_stream_t stream);
 
@@ -225,7 +227,9 @@ int molann_value_and_vjp_f32(molann_plan* plan, const float* x, const float* gra
 
 /* molann_forward_packed_f32 that also writes features[N, feature_dim] (what molann_features_f32 would give), for a
  * backward through molann_mlp_backward_f32 + molann_features_backward_f32 without the recompute.  Plans whose MLP
- * is fused into the lane kernel (the ones molann_plan_supports_backward accepts with an MLP); same `out` bit for bit. */
+ * is fused into the lane kernel, and large-frame plans with a head within the fused MLP's limits (the features are written
+ * where the caller keeps them and the head reads them there) - the ones molann_plan_supports_backward accepts with an MLP;
+ * same `out` bit for bit. */
 int molann_forward_train_f32(molann_plan* plan, const float* x, int64_t n_frames, float* out, float* features,
                              molann_stream_t stream);
 

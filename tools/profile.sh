@@ -17,7 +17,7 @@ for CTRS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_
             "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc$i" -- python3 $ARGS > /dev/null 2> "$OUT/pmc$i.err"
-  find "$OUT/pmc$i" -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "frames_|mlp_mfma|molann_mlp_chain|pack_|molann_lane_jit" "$1" >> "$2"' _ {} "$OUT/pmc${i}_counters.csv" \;
+  find "$OUT/pmc$i" -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "frames_|mlp_mfma|mlp_lane_kernel|molann_mlp_chain|pack_|molann_lane_jit" "$1" >> "$2"' _ {} "$OUT/pmc${i}_counters.csv" \;
 done
 python3 tools/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1
 rm -rf "$OUT"/trace "$OUT"/pmc[0-9] 
