@@ -220,12 +220,19 @@ def _p1():
                     rigid_motion=True, description="166-atom chain, Kabsch on 42 atoms + 8 dihedrals (d=16) + MLP [16,32,8]")
 
 
+def _p2():
+    # the reference's own use of the alignment: aligned POSITIONS of a subset of atoms as the encoder's input (README.rst: feature type 'position')
+    sel = tuple(range(2, 167, 4))
+    return Workload("P2", _peptide_xyz(), [(POSITION, sel)], align=sel, mlp_dims=[126, 64, 32, 2], frames=1 << 20, rigid_motion=True,
+                    description="166-atom chain, Kabsch on 42 atoms + their aligned positions (d=126) + MLP [126,64,32,2]")
+
+
 def _a5():
     return Workload("A5", _peptide_xyz(), [], align=tuple(range(2, 167, 4)), frames=1 << 20, rigid_motion=True, kind="align",
                     description="166-atom chain, AlignmentLayer.forward alone (Kabsch on 42 atoms, all 166 atoms written back)")
 
 
-_FACTORIES = {"A3": _a3, "A4": _a4, "A5": _a5, "P1": _p1, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
+_FACTORIES = {"A3": _a3, "A4": _a4, "A5": _a5, "P1": _p1, "P2": _p2, "C1": _c1, "C1s": _c1_sorted, "C2": _c2, "C3": _c3, "C3p": _c3p, "C4": _c4, "C5": _c5}
 
 
 def get_workload(name):
