@@ -79,7 +79,9 @@ class GraphedForces(GraphedForward):
     identity as cotangent: `g = GraphedForces(model, x.expand(d_out, -1, -1).contiguous()); y = g(xr)[0]; J = g.vjp(torch.eye(d_out))`.
 
     The backward graph holds one launch of `molann_backward_f32` (the one-pass kernel recomputes the forward from the static x:
-    nothing else links the two graphs), built and warmed before capture.  `recapture()` after changing parameters."""
+    nothing else links the two graphs), built and warmed before capture.  Models on frames of a few hundred atoms with a small
+    head (no one-pass kernel: wave-per-frame preprocessing) are captured as forward-with-kept-features and the two-launch backward
+    on them (`_recapture_kept_features`).  `recapture()` after changing parameters."""
 
     def recapture(self):
         super(GraphedForces, self).recapture()
@@ -87,6 +89,9 @@ class GraphedForces(GraphedForward):
         plan = self.model.plan_for(x) if hasattr(self.model, "plan_for") else None
         if plan is None or not plan.supports_backward():
             raise NotImplementedError("GraphedForces needs a model served by one fused plan with a backward kernel")
+        self._kept = False
+        if plan.backward_kind() == 1 and plan.kernel_family == 1:
+            return self._recapture_kept_features(plan)
         if plan.backward_kind() != 2:
             # the three-launch backward orders its shared workspace with plan-owned events and a side stream: not capturable
             raise NotImplementedError("GraphedForces needs the one-pass backward kernel (molann_plan_backward_kind == 2); this plan's "
@@ -109,6 +114,44 @@ class GraphedForces(GraphedForward):
             plan.backward(x, self.static_dy, self.static_dx, None)
         return self
 
+    def _recapture_kept_features(self, plan):
+        """Frames served by the wave-per-frame kernels with a small head (a peptide of a few hundred atoms): no one-pass kernel,
+        but the three entry points of the kept-features backward - `molann_forward_train_f32`, `molann_mlp_backward_f32` without
+        parameter gradients, `molann_features_backward_f32` - only enqueue on the stream they are given (no workspace, no side
+        stream, no events), so they capture: the forward graph keeps the features, the backward graph is the other two."""
+        x = self.static_x
+        n = x.shape[0]
+        self._plan, self._kept = plan, True
+        self.static_y = torch.empty((n, plan.out_dim), dtype=torch.float32, device=x.device)
+        self.static_y2 = self.static_y
+        self.static_f = torch.empty((n, plan.feature_dim), dtype=torch.float32, device=x.device)
+        self.static_gf = torch.empty_like(self.static_f)
+        self.static_dy = torch.zeros_like(self.static_y)
+        self.static_dx = torch.empty_like(x)
+
+        def fwd():
+            plan.forward_train(x, self.static_y, self.static_f)
+
+        def bwd():
+            plan.mlp_backward(self.static_f, self.static_dy, self.static_gf, None)
+            plan.features_backward(x, self.static_gf, self.static_dx)
+
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side), torch.cuda.device(x.device):
+            for _ in range(self._warmup):       # compiles the MLP's backward kernel outside the capture
+                fwd()
+                bwd()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.cuda.device(x.device):
+            fwd()
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph), torch.cuda.device(x.device):
+            bwd()
+        return self
+
     def value_and_vjp(self, x, dy):
         """``(y, dx)`` of one launch of `molann_value_and_vjp_f32` on fresh `x` and `dy` (no graph: a direct launch from an idle
         stream costs less host time than a graph replay plus the two copies into its static buffers) into this object's
@@ -117,6 +160,12 @@ class GraphedForces(GraphedForward):
         if x.shape != self.static_x.shape or dy.shape != self.static_dy.shape:
             raise ValueError("GraphedForces was captured for %s / %s, got %s / %s" % (tuple(self.static_x.shape), tuple(self.static_dy.shape),
                                                                                     tuple(x.shape), tuple(dy.shape)))
+        if self._kept:       # no single launch for these plans: the two replays
+            self.static_x.copy_(x)
+            self.static_dy.copy_(dy)
+            self.graph.replay()
+            self.bwd_graph.replay()
+            return self.static_y, self.static_dx
         return self.model.value_and_vjp(x, dy, into=(self.static_y2, self.static_dx))
 
     def vjp(self, dy):

@@ -338,12 +338,14 @@ def test_hip_graph_replay_matches_eager(hip_device):
             assert torch.equal(got.cpu(), want), cfg
 
 
-def test_hip_graph_forces_match_autograd(hip_device):
+@pytest.mark.parametrize("cfg", ["C3", "P1"])
+def test_hip_graph_forces_match_autograd(cfg, hip_device):
     """GraphedForces: the values and the vector-Jacobian product of a small batch as two HIP graph replays (a collective variable
-    differentiated at every MD step), against eager autograd; with its latency per call."""
+    differentiated at every MD step), against eager autograd; with its latency per call.  C3: the one-pass backward kernel; P1
+    (166 atoms, wave-per-frame preprocessing): the forward that keeps its features and the two-launch backward on them."""
     import time
     from molann_amd.graph import GraphedForces
-    w = wl.get_workload("C3")
+    w = wl.get_workload(cfg)
     model = workload_model(w, hip_device).requires_grad_(False)
     for n in (1, 64):
         g = GraphedForces(model, w.make_frames(n, seed=1).to(hip_device))
@@ -363,7 +365,9 @@ def test_hip_graph_forces_match_autograd(hip_device):
             g(x)
             g.vjp(dy)
         torch.cuda.synchronize()
-        print("GraphedForces, %d frame(s): %.1f us per values + forces" % (n, (time.perf_counter() - t0) / 200 * 1e6))
+        print("GraphedForces, %s, %d frame(s): %.1f us per values + forces" % (cfg, n, (time.perf_counter() - t0) / 200 * 1e6))
+        y2, dx2 = g.value_and_vjp(x, dy)
+        assert float((y2 - ye.detach()).abs().max()) <= 1e-6 and float((dx2 - dxe).abs().max()) <= 1e-6 * max(1.0, float(dxe.abs().max()))
     # the whole Jacobian of one frame's values: a batch of d_out copies of the frame, the identity as cotangent
     d_out = w.out_dim()
     x1 = w.make_frames(1, seed=9).to(hip_device)
