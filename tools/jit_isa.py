@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (no GPU needed): the plan-specialised lane kernel of a workload as source and gfx950 ISA, with its
-resource usage and instruction mix.   python tools/jit_isa.py [C3] [outdir] [--bwd | --mlp-bwd | --ring-bwd | --save-feat | --wide] [--no-mlp | --dims=6,32,32,8] [extra hipcc flags...]"""
+resource usage and instruction mix.   python tools/jit_isa.py [C3] [outdir] [--bwd | --mlp-bwd | --ring-bwd | --save-feat | --wide | --chain] [--no-mlp | --dims=6,32,32,8] [extra hipcc flags...]"""
 import collections, ctypes, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,7 @@ from molann_amd import _capi, workloads as wl
 _desc = _capi.workload_desc
 
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
-flags = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("--bwd", "--mlp-bwd", "--ring-bwd", "--no-mlp", "--save-feat", "--wide") and not a.startswith("--dims=")]
+flags = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("--bwd", "--mlp-bwd", "--ring-bwd", "--no-mlp", "--save-feat", "--wide", "--chain", "--bf16") and not a.startswith("--dims=")]
 name = args[0] if args else "C3"
 out = args[1] if len(args) > 1 else "/tmp/jit_%s" % name
 os.makedirs(out, exist_ok=True)
@@ -21,8 +21,10 @@ for a in sys.argv[1:]:
         ld = (ctypes.c_int32 * len(dims))(*dims)
         d.n_layers, d.layer_dims = len(dims) - 1, ld
         keep.append(ld)
+if "--bf16" in sys.argv:
+    d.mlp_precision = _capi.MLP_BF16
 buf = ctypes.create_string_buffer(1 << 22)
-rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 128 if "--wide" in sys.argv else 32 if "--save-feat" in sys.argv else 18 if "--ring-bwd" in sys.argv else 10 if "--mlp-bwd" in sys.argv else 2 if "--bwd" in sys.argv else 0, buf, 1 << 22)
+rc = _capi.lib().molann_debug_jit(ctypes.byref(d), 4 if "--chain" in sys.argv else 128 if "--wide" in sys.argv else 32 if "--save-feat" in sys.argv else 18 if "--ring-bwd" in sys.argv else 10 if "--mlp-bwd" in sys.argv else 2 if "--bwd" in sys.argv else 0, buf, 1 << 22)
 assert rc > 0, rc
 src = os.path.join(out, "k.hip")
 open(src, "w").write(buf.value.decode())

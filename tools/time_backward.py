@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 w = wl.get_workload(name)
 model = wl.build_model(w, dev)
 xs = [w.make_frames(w.frames, device=dev, seed=i) for i in range(3)]
-G = torch.randn((w.frames, w.out_dim()), device=dev)
+G = torch.randn((w.frames, w.n_atoms, 3) if w.kind == "align" else (w.frames, w.out_dim()), device=dev)
 def step(x, need_x):
     x = x.detach().requires_grad_(need_x)
     out = model(x)

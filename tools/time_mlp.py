@@ -19,7 +19,7 @@ if r == 1:
     feats.append((_capi.FEAT_BOND, [k, k + 1]))
 elif r == 2:
     feats.append((_capi.FEAT_DIHEDRAL, [k, k + 1, k + 2, k + 3]))
-plan = _capi.Plan(k + 8, features=feats, layer_dims=dims, activation=_capi.ACT_TANH,
+plan = _capi.Plan(k + 8, features=feats, layer_dims=dims, activation=int(os.environ.get("ACT", _capi.ACT_TANH)),
                   mlp_precision=_capi.MLP_BF16 if prec == "bf16" else _capi.MLP_F32)
 ws = [torch.randn(j, i, device=dev) / i ** 0.5 for i, j in zip(dims[:-1], dims[1:])]
 bs = [torch.zeros(j, device=dev) for j in dims[1:]]
