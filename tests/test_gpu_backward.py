@@ -607,3 +607,48 @@ def test_small_head_behind_wave_per_frame_kernels_trains_through_the_hip_kernels
     for lin, wr, br in zip(lins, ws, bs):
         assert float((lin.weight.grad.cpu().double() - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
         assert float((lin.bias.grad.cpu().double() - br.grad).abs().max()) <= 2e-4 * max(1.0, float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("n_inp,kernel", [(90, "frames_align_bwd_regs_kernel<W=1,U=1>"), (166, "frames_align_bwd_regs_kernel<W=1,U=1>"),
+                                          (700, "frames_align_bwd_regs_kernel<W=1,U=3>"), (1537, "frames_align_bwd_regs_kernel<W=4,U=2>"),
+                                          (5000, "frames_align_bwd_regs_kernel<W=8,U=3>"), (7001, "frames_align_bwd_regs_kernel<W=8,U=4>"),
+                                          (8300, "frames_wave_bwd")])
+def test_dense_alignment_gradient(n_inp, kernel, hip_device, monkeypatch):
+    """AlignmentLayer.forward under autograd on frames the lane kernels do not serve: the forward through the alignment kernels,
+    the gradient through frames_align_bwd_regs_kernel (frame and cotangent in registers; up to 8192 atoms, the gather kernel
+    beyond), against torch autograd of the float64 oracle and against the gather kernel (MOLANN_NO_DENSE_ALIGN=1); batch sizes
+    around the grid's, the input never written, atoms outside the alignment set included."""
+    from molann_amd.ann import last_launch_info
+    rng = np.random.default_rng(n_inp)
+    xyz = np.cumsum(rng.normal(size=(n_inp, 3)) * 0.9, axis=0).astype(np.float32)
+    xyz -= xyz.mean(axis=0, keepdims=True)
+    u = Universe(xyz)
+    align = sorted(rng.choice(n_inp, size=int(rng.choice([3, 40, min(300, n_inp // 2)])), replace=False).tolist())
+    layer = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms).to(hip_device)
+    ref_x = mo.center_reference(torch.from_numpy(xyz[align])).double()
+    g = torch.Generator().manual_seed(n_inp)
+    for n in (1, 37, 600 if n_inp <= 1537 else 90):
+        x = (torch.from_numpy(xyz).unsqueeze(0) + 0.2 * torch.randn((n, n_inp, 3), generator=g)).float().contiguous()
+        G = torch.randn(x.shape, generator=g)
+        xg = x.to(hip_device).requires_grad_(True)
+        y = layer(xg)
+        fwd_info = last_launch_info(layer)
+        (y * G.to(hip_device)).sum().backward()
+        info = last_launch_info(layer)
+        assert kernel in info, info
+        if "frames_align_bwd_regs_kernel" in kernel:
+            assert "frames_align_batch_kernel" in fwd_info or "frames_align_regs_kernel" in fwd_info, fwd_info
+        xx = x.double().requires_grad_(True)
+        want = mo.align_forward(xx, align, ref_x)
+        (want * G.double()).sum().backward()
+        assert float((y.detach().cpu().double() - want.detach()).abs().max()) <= 1e-5 + 1e-6 * float(want.detach().abs().max())
+        scale = float(xx.grad.abs().max())
+        assert float((xg.grad.cpu().double() - xx.grad).abs().max()) <= 2e-4 * scale, (n, info)
+        assert torch.equal(xg.detach().cpu(), x)
+    if "frames_align_bwd_regs_kernel" in kernel:
+        monkeypatch.setenv("MOLANN_NO_DENSE_ALIGN", "1")
+        layer2 = AlignmentLayer(u.atoms_by_number([a + 1 for a in align]), u.atoms).to(hip_device)
+        x2 = x.to(hip_device).requires_grad_(True)
+        (layer2(x2) * G.to(hip_device)).sum().backward()
+        assert "frames_align_bwd_regs_kernel" not in last_launch_info(layer2)
+        assert float((x2.grad - xg.grad).abs().max()) <= 2e-5 * scale
