@@ -474,6 +474,50 @@ at::Tensor run_backward_mlp_hip(const at::Tensor& feat, std::vector<int64_t> des
     return gp;
 }
 
+// {grad_x, flat parameter gradients} from the features run_train kept, for plans whose backward is the launches on kept features
+// (molann_plan_backward_kind == 1: wave-per-frame preprocessing with a small head): the MLP's backward, then the preprocessing's
+std::vector<at::Tensor> run_backward_kept_hip(const at::Tensor& x_in, const at::Tensor& feat, std::vector<int64_t> desc, const at::Tensor& ref_x,
+                                              std::vector<at::Tensor> weights, std::vector<at::Tensor> biases, const at::Tensor& grad_out,
+                                              bool need_x, bool need_params) {
+    check_x(x_in, desc);
+    TORCH_CHECK(desc[1] == KIND_FORWARD && x_in.scalar_type() == at::kFloat && feat.dim() == 2 && feat.scalar_type() == at::kFloat,
+                "molann::run_backward_kept: float32 forward plans only");
+    const at::Tensor x = x_in.contiguous();
+    const at::Tensor f = feat.contiguous();
+    const c10::DeviceGuard guard(x.device());
+    auto e = entry_for(desc, x, ref_x);
+    const int64_t n = x.size(0);
+    TORCH_CHECK(f.size(0) == n && f.size(1) == e->feature_dim, "molann::run_backward_kept: features are [", n, ", ", e->feature_dim, "], got ", f.sizes());
+    at::Tensor g = grad_out.to(at::kFloat).reshape({n, e->out_dim}).contiguous();
+    at::Tensor gx = need_x ? at::empty_like(x) : at::empty({0}, x.options());
+    at::Tensor gp = need_params ? at::zeros({molann_plan_grad_params_size(e->plan)}, x.options()) : at::empty({0}, x.options());
+    if (n == 0) {
+        if (need_x) gx.zero_();
+        return {gx, gp};
+    }
+    at::Tensor gf = need_x ? at::empty_like(f) : at::empty({0}, f.options());
+    hipStream_t stream = c10::hip::getCurrentHIPStream(x.get_device()).stream();
+    std::lock_guard<std::mutex> lock(e->mu);
+    sync_live(*e, x, ref_x, weights, biases, stream);
+    check(molann_mlp_backward_f32(e->plan, f.data_ptr<float>(), g.data_ptr<float>(), n, need_x ? gf.data_ptr<float>() : nullptr,
+                                  need_params ? gp.data_ptr<float>() : nullptr, stream),
+          "molann_mlp_backward_f32");
+    if (need_x)
+        check(molann_features_backward_f32(e->plan, x.data_ptr<float>(), gf.data_ptr<float>(), n, gx.data_ptr<float>(), stream),
+              "molann_features_backward_f32");
+    return {gx, gp};
+}
+
+// molann_plan_backward_kind of the plan of `desc` on x's device: 2 one pass over x, 1 launches on kept features, 0 none
+int64_t backward_kind(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x) {
+    check_x(x, desc);
+    TORCH_CHECK(x.is_cuda(), "molann::backward_kind: x must be a device tensor");
+    const c10::DeviceGuard guard(x.device());
+    auto e = entry_for(desc, x, ref_x);
+    std::lock_guard<std::mutex> lock(e->mu);
+    return molann_plan_backward_kind(e->plan);
+}
+
 // 1 if the plan of `desc` on x's device has backward kernels (molann_plan_supports_backward), else 0
 int64_t supports_backward(const at::Tensor& x, std::vector<int64_t> desc, const at::Tensor& ref_x) {
     check_x(x, desc);
@@ -596,6 +640,16 @@ at::Tensor call_run_backward_mlp(const at::Tensor& feat, const std::vector<int64
     return op.call(feat, desc, ref_x, weights, biases, grad_out);
 }
 
+std::vector<at::Tensor> call_run_backward_kept(const at::Tensor& x, const at::Tensor& feat, const std::vector<int64_t>& desc, const at::Tensor& ref_x,
+                                               const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases, const at::Tensor& grad_out,
+                                               bool need_x, bool need_params) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("molann::run_backward_kept", "")
+                         .typed<std::vector<at::Tensor>(const at::Tensor&, const at::Tensor&, std::vector<int64_t>, const at::Tensor&, std::vector<at::Tensor>,
+                                                        std::vector<at::Tensor>, const at::Tensor&, bool, bool)>();
+    return op.call(x, feat, desc, ref_x, weights, biases, grad_out, need_x, need_params);
+}
+
 std::vector<int64_t> features_only(const std::vector<int64_t>& desc);
 at::Tensor activation(int64_t code, const at::Tensor& t);
 
@@ -689,7 +743,11 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
         // recomputes everything, nothing to keep.  Parameters only (x is data): the MLP's backward alone, on the features
         // this forward keeps - no second pass over x.
         at::Tensor out, feat;
-        if (desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD && !x.requires_grad() && x.scalar_type() == at::kFloat && x.is_cuda()) {
+        // (x wants a gradient too: kept features still pay where the backward is launches on them anyway - backward kind 1, a small
+        // head behind the wave-per-frame kernels - instead of a recompute of the features inside molann_backward_f32)
+        bool keep = desc.size() >= DESC_HEAD && desc[1] == KIND_FORWARD && x.scalar_type() == at::kFloat && x.is_cuda();
+        if (keep && x.requires_grad()) keep = x.size(0) > 0 && backward_kind(x, desc, ref_x) == 1;
+        if (keep) {
             std::vector<at::Tensor> r = call_run_train(x, desc, ref_x, weights.vec(), biases.vec());
             out = r[0];
             if (r[1].numel() > 0 || x.size(0) == 0) feat = r[1];
@@ -734,6 +792,8 @@ struct RunFunction : public torch::autograd::Function<RunFunction> {
             at::AutoDispatchBelowADInplaceOrView below;
             if (ctx->saved_data["kept_features"].toBool() && !need_x) {
                 g = {at::Tensor(), need_p ? call_run_backward_mlp(saved[2 + 2 * nl], desc, ref_x, weights, biases, grad_outputs[0]) : at::Tensor()};
+            } else if (ctx->saved_data["kept_features"].toBool() && backward_kind(x, desc, ref_x) == 1) {
+                g = call_run_backward_kept(x, saved[2 + 2 * nl], desc, ref_x, weights, biases, grad_outputs[0], need_x, need_p);
             } else {
                 g = call_run_backward(x, desc, ref_x, weights, biases, grad_outputs[0], need_x, need_p);
             }
@@ -834,6 +894,9 @@ TORCH_LIBRARY(molann, m) {
           "bool need_params) -> Tensor[]");
     m.def("run_train(Tensor x, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor[]");
     m.def("run_backward_mlp(Tensor feat, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out) -> Tensor");
+    m.def("run_backward_kept(Tensor x, Tensor feat, int[] desc, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, bool need_x, "
+          "bool need_params) -> Tensor[]");
+    m.def("backward_kind(Tensor x, int[] desc, Tensor ref_x) -> int", backward_kind);
     m.def("register_desc(int[] desc) -> int", register_desc);
     m.def("run_h(Tensor x, int handle, Tensor ref_x, Tensor[] weights, Tensor[] biases) -> Tensor");
     m.def("value_and_vjp_h(Tensor x, int handle, Tensor ref_x, Tensor[] weights, Tensor[] biases, Tensor grad_out, Tensor[] into) -> Tensor[]");
@@ -853,6 +916,7 @@ TORCH_LIBRARY_IMPL(molann, CUDA, m) { // ROCm builds of torch name the HIP devic
     m.impl("run_backward", run_backward_hip);
     m.impl("run_train", run_train_hip);
     m.impl("run_backward_mlp", run_backward_mlp_hip);
+    m.impl("run_backward_kept", run_backward_kept_hip);
     m.impl("value_and_vjp", value_and_vjp_hip);
     m.impl("run_h", run_h_hip);
     m.impl("value_and_vjp_h", value_and_vjp_h_hip);
