@@ -610,12 +610,12 @@ def test_small_head_behind_wave_per_frame_kernels_trains_through_the_hip_kernels
 
 
 @pytest.mark.parametrize("n_inp,kernel", [(90, "frames_align_bwd_regs_kernel<W=1,U=1>"), (166, "frames_align_bwd_regs_kernel<W=1,U=1>"),
-                                          (700, "frames_align_bwd_regs_kernel<W=1,U=3>"), (1537, "frames_align_bwd_regs_kernel<W=4,U=2>"),
-                                          (5000, "frames_align_bwd_regs_kernel<W=8,U=3>"), (7001, "frames_align_bwd_regs_kernel<W=8,U=4>"),
-                                          (8300, "frames_wave_bwd")])
+                                          (700, "frames_align_bwd_regs_kernel<W=1,U=3>"), (1537, "frames_align_bwd_regs_kernel<W=2,U=4>"),
+                                          (5000, "frames_align_bwd_regs_kernel<W=4,U=5>"), (7001, "frames_align_bwd_regs_kernel<W=8,U=4>"),
+                                          (12288, "frames_align_bwd_regs_kernel<W=8,U=6>"), (12400, "frames_wave_bwd")])
 def test_dense_alignment_gradient(n_inp, kernel, hip_device, monkeypatch):
     """AlignmentLayer.forward under autograd on frames the lane kernels do not serve: the forward through the alignment kernels,
-    the gradient through frames_align_bwd_regs_kernel (frame and cotangent in registers; up to 8192 atoms, the gather kernel
+    the gradient through frames_align_bwd_regs_kernel (the cotangent in registers; up to 12 288 atoms, the gather kernel
     beyond), against torch autograd of the float64 oracle and against the gather kernel (MOLANN_NO_DENSE_ALIGN=1); batch sizes
     around the grid's, the input never written, atoms outside the alignment set included."""
     from molann_amd.ann import last_launch_info
